@@ -1,0 +1,202 @@
+/*
+ * mi_instance_pipeline.h — C ABI of the MI355X (gfx950) instance pipeline.
+ *
+ * One call per frame replaces, for every instance of a scene, this part of
+ * farnoy/renderer (paths relative to the reference checkout):
+ *
+ *   src/ecs.rs:52-64       systems::model_matrix_calculation   M = T(p)·R(q)·S(s)
+ *   src/ecs.rs:138-181     systems::aabb_calculation           mesh AABB -> world AABB
+ *   src/renderer/systems/cull_pipeline.rs:99-120  coarse_culling   AABB vs 6 planes
+ *   src/ecs.rs:117-136     systems::assign_draw_index          draw_index = array index
+ *   src/renderer.rs:2266-2288  model_matrices_upload           model[draw_index] = M
+ *   src/renderer/systems/cull_pipeline.rs:534-577 cull_pass    per-instance draw command
+ *   src/renderer/helpers.rs:3-11  pick_lod                     LOD 1 beyond 10 units
+ *   src/shaders/generate_work.comp:61-67          command header fields
+ *   src/shaders/compact_draw_stream.comp:34-63    stream compaction + count
+ *
+ * The reference has no plugin API for this path; the boundary follows the one
+ * FFI precedent in the repository, the `vma` crate (vma/src/lib.rs:31-64,
+ * src/renderer/device/alloc.rs:192-226): opaque handle, plain #[repr(C)] POD
+ * parameter structs, integer status returns (0 = success), out-pointers,
+ * explicit create/destroy, no callbacks, nothing unwinds across the boundary.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, and is
+ * implemented only by the HIP path: there is no CPU backend behind this ABI.
+ * Without a usable gfx950 device mip_create fails with MIP_ERR_NO_DEVICE.
+ */
+#ifndef MI_INSTANCE_PIPELINE_H
+#define MI_INSTANCE_PIPELINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIP_ABI_VERSION 1u
+
+/* ---- status codes (0 = success, negative = error; like VkResult in vma) ---- */
+#define MIP_OK 0
+#define MIP_ERR_INVALID_ARGUMENT (-1) /* NULL pointer, bad size, mesh id out of range ... */
+#define MIP_ERR_NO_DEVICE (-2)        /* no HIP device / not gfx950 / ordinal out of range */
+#define MIP_ERR_OUT_OF_MEMORY (-3)    /* hipMalloc failed */
+#define MIP_ERR_CAPACITY (-4)         /* more instances / meshes than the context was created for */
+#define MIP_ERR_DEVICE (-5)           /* a HIP runtime call failed; see mip_last_error */
+#define MIP_ERR_NOT_READY (-6)        /* run before instances / mesh table were set */
+#define MIP_ERR_TIMEOUT (-7)          /* a bounded in-kernel wait expired; outputs are invalid */
+
+/* ---- MipConfig.flags ---- */
+#define MIP_CFG_TIMING 0x1u /* bracket every kernel with hipEvents (mip_get_timings) */
+
+/* ---- MipOutputs.flags ---- */
+#define MIP_OUT_HOST 0x0u   /* output pointers are host memory (copied back, synchronous) */
+#define MIP_OUT_DEVICE 0x1u /* output pointers are device memory of the context's GPU */
+#define MIP_OUT_ASYNC 0x2u  /* with MIP_OUT_DEVICE: return after enqueue; pair with mip_wait */
+
+/* Largest LOD chain the scene loader can produce: LOD0 + 5 simplified levels
+ * (src/renderer/systems/scene_loader.rs:740-753). */
+#define MIP_MAX_LODS 6u
+
+typedef struct MipContext MipContext; /* opaque; Send + Sync like VmaAllocator */
+
+typedef struct MipConfig {
+  uint32_t struct_size;   /* = sizeof(MipConfig); guards ABI drift */
+  int32_t device_ordinal; /* HIP device index of this process' GPU */
+  uint32_t max_instances; /* capacity; the reference's is 4096 (generate_work.comp:25-27) */
+  uint32_t max_meshes;    /* capacity of the mesh table */
+  uint32_t flags;         /* MIP_CFG_* */
+  uint32_t reserved;
+  void* stream; /* hipStream_t to enqueue on, or NULL for a stream owned by the context */
+} MipConfig;
+
+/* One entry per distinct mesh. Stands in for GltfMesh.aabb (src/renderer.rs:125),
+ * GltfMesh.index_buffers[lod].1 (index_len) and the ConsolidatedMeshBuffers
+ * vertex_offsets / index_offsets lookups (cull_pipeline.rs:540-548). */
+typedef struct MipMesh {
+  float aabb_min[3]; /* mesh-local box, finite */
+  float aabb_max[3];
+  uint32_t n_lods;                     /* 1..MIP_MAX_LODS */
+  uint32_t index_len[MIP_MAX_LODS];    /* indices in LOD k */
+  uint32_t index_offset[MIP_MAX_LODS]; /* offset of LOD k in the consolidated index buffer */
+  int32_t vertex_offset;               /* offset in the consolidated vertex buffer */
+} MipMesh;
+
+/* Byte-identical to VkDrawIndexedIndirectCommand (generate_work.comp:9-15,
+ * asserted against ash's struct at src/renderer.rs:178-185). */
+typedef struct MipDrawIndexedIndirectCommand {
+  uint32_t indexCount;
+  uint32_t instanceCount;
+  uint32_t firstIndex;
+  int32_t vertexOffset;
+  uint32_t firstInstance;
+} MipDrawIndexedIndirectCommand;
+
+/* Per-frame inputs. Everything else is resident on the device. */
+typedef struct MipFrame {
+  /* Camera.frustum_planes (src/ecs/camera_controller.rs:15-16): 6 x (nx,ny,nz,d),
+   * order left,right,bottom,top,near,far, outward-facing, not normalised
+   * (src/ecs.rs:83-90). Produced on the host by project_camera. */
+  float planes[24];
+  float cam_pos[3];           /* Camera.position, for pick_lod */
+  uint32_t first_instance_base; /* added to firstInstance: draw_index of instance 0 of this shard */
+  uint32_t first_index_base;    /* added to firstIndex (wrapping u32) */
+} MipFrame;
+
+typedef struct MipOutputs {
+  /* N x mat4, column-major, 64 B each: the `mat4 model[]` storage buffer
+   * (ModelData.model_buffer, src/renderer.rs:1225-1249). May be NULL. */
+  void* model;
+  /* ceil(N/32) words; bit (i & 31) of word (i >> 5) = !CoarseCulled[i]. May be NULL. */
+  uint32_t* visible_bitmap;
+  /* Up to N MipDrawIndexedIndirectCommand, compacted, ascending draw_index
+   * (IndirectCommandsBuffer). Entries past *draw_count are left untouched. May be NULL
+   * only together with draw_count. */
+  void* draw_cmds;
+  uint32_t* draw_count; /* IndirectCommandsCount.count */
+  /* Optional: Σ indexCount over the emitted commands (wrapping u32) = the firstIndex the
+   * next appended command would get, relative to first_index_base. Needed when shards
+   * of one scene are merged (mip_merge_draw_lists). May be NULL. */
+  uint32_t* draw_index_total;
+  /* Optional: N x {mins[3], maxs[3]} world AABB as the ECS `AABB` component holds it
+   * (src/ecs/components.rs:18-20). May be NULL. */
+  void* world_aabb;
+  uint32_t flags; /* MIP_OUT_* */
+  uint32_t reserved;
+} MipOutputs;
+
+typedef struct MipTimings {
+  uint64_t runs;              /* mip_run calls timed since create / last reset */
+  double last_kernel_ms;      /* hipEvent time of the pipeline kernel of the last run */
+  double total_kernel_ms;     /* sum over `runs` */
+  double last_merge_ms;       /* same for mip_merge_draw_lists */
+  double total_merge_ms;
+  uint64_t merges;
+} MipTimings;
+
+/* Chunk header used by mip_merge_draw_lists: what each rank contributes to the
+ * all-gather in front of its commands. 32 B so the commands stay 16-B aligned. */
+typedef struct MipShardHeader {
+  uint32_t draw_count;
+  uint32_t draw_index_total;
+  uint32_t reserved[6];
+} MipShardHeader;
+
+uint32_t mip_abi_version(void);
+
+/* Create a context on cfg->device_ordinal. Allocates device storage for
+ * max_instances / max_meshes. Returns MIP_OK and writes *out, or a negative code
+ * (then *out = NULL). Never aborts. */
+int32_t mip_create(const MipConfig* cfg, MipContext** out);
+
+/* Frees everything the context owns. NULL is a no-op. */
+void mip_destroy(MipContext* ctx);
+
+/* Copy the mesh table to the device (caller keeps its memory). m <= max_meshes.
+ * Bounds must be finite and n_lods in 1..MIP_MAX_LODS. */
+int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m);
+
+/* Upload the instance columns: SoA, tightly packed, draw_index = array index
+ * (assign_draw_index for a single-archetype static scene, src/ecs.rs:117-136).
+ *   pos_xyz  n x 3 floats   Position(Point3<f32>)
+ *   rot_ijkw n x 4 floats   Rotation(UnitQuaternion<f32>), stored [i,j,k,w]; NOT renormalised
+ *   scale    n floats       Scale(f32)
+ *   mesh_id  n u32          index into the mesh table; every id must be < m
+ * Host pointers; copied. Static scenes call this once. n may be 0. */
+int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* rot_ijkw,
+                          const float* scale, const uint32_t* mesh_id, uint32_t n);
+
+/* Same, from DEVICE pointers of the context's GPU (device-to-device copies; mesh ids are
+ * not validated — the caller guarantees id < m). */
+int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw,
+                                 const void* scale, const void* mesh_id, uint32_t n);
+
+/* One frame: model matrices, world AABBs, visibility, compacted draw commands.
+ * Call from one thread at a time per context. Synchronous on return unless
+ * MIP_OUT_ASYNC. */
+int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out);
+
+/* Block until everything enqueued by this context has finished; reports a
+ * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
+int32_t mip_wait(MipContext* ctx);
+
+/* Merge `n_chunks` shard draw lists (each: MipShardHeader followed by its commands,
+ * chunks `chunk_stride_bytes` apart, as an all-gather lays them out; DEVICE memory) into
+ * one contiguous list in shard order, adding to each shard's firstIndex the
+ * draw_index_total of all earlier shards. out_count[0] = total commands,
+ * out_count[1] = total indices (so out_count needs room for 2 words). DEVICE pointers. Enqueued on the context's stream; synchronous unless
+ * `async` is non-zero. `out_cmds` needs room for the sum of the counts. */
+int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks,
+                             uint64_t chunk_stride_bytes, void* out_cmds, uint32_t* out_count,
+                             int32_t async);
+
+const char* mip_last_error(const MipContext* ctx);
+int32_t mip_get_timings(MipContext* ctx, MipTimings* out);
+int32_t mip_reset_timings(MipContext* ctx);
+
+/* Number of instances currently resident (set by mip_set_instances*). */
+uint32_t mip_instance_count(const MipContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_INSTANCE_PIPELINE_H */

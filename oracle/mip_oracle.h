@@ -1,0 +1,131 @@
+/*
+ * mip_oracle.h — CPU oracle of the instance pipeline. TEST INFRASTRUCTURE ONLY.
+ *
+ * A scalar, plain-C restatement of the reference's per-frame instance path
+ * (farnoy/renderer; citations are paths in the reference checkout). Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product library (renderer_amd/csrc) never links, includes or calls it.
+ *
+ * PARITY UNPINNED: the reference has no tests, fixtures or golden vectors for this
+ * path, it is nightly Rust and cannot be built here, and the
+ * arithmetic it calls lives in crates that are not vendored (nalgebra 0.29.0,
+ * nalgebra-glm 0.15.0, ncollide3d 0.32.0 — Cargo.lock). The operation order below
+ * restates those crates' published algorithms (column-axpy gemm/gemv, the 3- and
+ * 4-wide dot special cases, UnitQuaternion::to_rotation_matrix,
+ * AABB::from_half_extents/center/half_extents) anchored on the reference's call
+ * sites; nothing here could be checked against an execution of the reference.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile). All
+ * arithmetic is IEEE-754 binary32, round-to-nearest-even, no fused multiply-add.
+ */
+#ifndef MIP_ORACLE_H
+#define MIP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LODS 6
+
+/* Same layout as MipMesh in include/mi_instance_pipeline.h. */
+typedef struct OrcMesh {
+  float aabb_min[3];
+  float aabb_max[3];
+  uint32_t n_lods;
+  uint32_t index_len[ORC_MAX_LODS];
+  uint32_t index_offset[ORC_MAX_LODS];
+  int32_t vertex_offset;
+} OrcMesh;
+
+/* VkDrawIndexedIndirectCommand, src/shaders/generate_work.comp:9-15 */
+typedef struct OrcDrawCmd {
+  uint32_t indexCount;
+  uint32_t instanceCount;
+  uint32_t firstIndex;
+  int32_t vertexOffset;
+  uint32_t firstInstance;
+} OrcDrawCmd;
+
+/* 4x4 matrices are column-major float[16]: m[c*4 + r] (glm::Mat4 / nalgebra storage). */
+
+/* nalgebra UnitQuaternion::to_homogeneous (via to_rotation_matrix); q = [i,j,k,w]. */
+void orc_quat_to_homogeneous(const float q[4], float m[16]);
+/* glm::translation / glm::scaling (uniform). */
+void orc_translation(const float p[3], float m[16]);
+void orc_scaling(float s, float m[16]);
+/* nalgebra Matrix4 * Matrix4 for statically sized matrices: per output column a gemv built
+ * from axpy steps over the columns of `a`, left to right. */
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]);
+/* nalgebra Matrix4 * Vector4 (same gemv). */
+void orc_mat4_mul_vec4(const float a[16], const float v[4], float out[4]);
+
+/* src/ecs.rs:52-64 model_matrix_calculation: translation(p) * rot.to_homogeneous() * scaling(s). */
+void orc_model_matrix(const float pos[3], const float rot_ijkw[4], float scale, float m[16]);
+
+/* src/ecs.rs:138-181 aabb_calculation. */
+void orc_world_aabb(const float m[16], const float mesh_min[3], const float mesh_max[3],
+                    float mins[3], float maxs[3]);
+
+/* src/renderer/systems/cull_pipeline.rs:99-120 coarse_culling; returns CoarseCulled (1 = culled). */
+int orc_coarse_culled(const float mins[3], const float maxs[3], const float planes[24]);
+
+/* src/renderer/helpers.rs:3-11 pick_lod; returns the LOD index (0 or 1). */
+uint32_t orc_pick_lod(uint32_t n_lods, const float cam_pos[3], const float mesh_pos[3]);
+
+/* src/ecs.rs:66-91 project_camera. The planes are an INPUT of the path (computed once per
+ * frame on the host); this restatement exists to make default-camera test inputs and is
+ * not claimed to match nalgebra-glm's look_at_lh bit for bit (it builds the view matrix
+ * from the basis vectors directly instead of through a quaternion). cam_rot = [i,j,k,w]. */
+void orc_project_camera(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect,
+                        float fovy_degrees, float near_z, float far_z, float planes[24]);
+
+/* src/renderer/systems/cull_pipeline.rs:498-577 + src/shaders/generate_work.comp:61-67:
+ * zero-fill cmds[0..n), then for every instance in draw_index order that is not
+ * coarse-culled write cmds[i]; instance-level contract: indexCount = index_len of the
+ * picked LOD. Returns Σ index_len (the final index_offset_in_output, wrapping u32). */
+uint32_t orc_emit_draw_commands(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id,
+                                const uint8_t* coarse_culled, const OrcMesh* meshes,
+                                const float cam_pos[3], uint32_t first_instance_base,
+                                uint32_t first_index_base, OrcDrawCmd* cmds);
+
+/* src/shaders/compact_draw_stream.comp:34-63 with its intended semantics (all n entries)
+ * and the stable member of its outcome set (ascending index): keep indexCount > 0.
+ * In-place capable (out may equal cmds). Returns count. */
+uint32_t orc_compact_draw_stream(const OrcDrawCmd* cmds, uint32_t n, OrcDrawCmd* out);
+
+typedef struct OrcOutputs {
+  float* model;             /* n*16, may be NULL */
+  float* world_aabb;        /* n*6 (mins, maxs), may be NULL */
+  uint32_t* visible_bitmap; /* ceil(n/32) words, may be NULL */
+  uint8_t* coarse_culled;   /* n bytes, may be NULL */
+  OrcDrawCmd* draw_cmds;    /* n entries, may be NULL */
+  uint32_t draw_count;
+  uint32_t draw_index_total;
+} OrcOutputs;
+
+/* The whole path on one thread, literally: matrices -> AABBs -> cull -> emit -> compact.
+ * Returns 0, or -1 on a mesh id >= m / allocation failure. */
+int orc_run(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale,
+            const uint32_t* mesh_id, const OrcMesh* meshes, uint32_t m, const float planes[24],
+            const float cam_pos[3], uint32_t first_instance_base, uint32_t first_index_base,
+            OrcOutputs* out);
+
+/* Same result on `threads` pthreads (static contiguous chunks, per-chunk emission, serial
+ * prefix over chunks). Used for the CPU baseline. */
+int orc_run_mt(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale,
+               const uint32_t* mesh_id, const OrcMesh* meshes, uint32_t m, const float planes[24],
+               const float cam_pos[3], uint32_t first_instance_base, uint32_t first_index_base,
+               OrcOutputs* out, uint32_t threads);
+
+/* Concatenate shard draw lists in shard order, rebasing firstIndex by the index totals of
+ * the earlier shards (what mip_merge_draw_lists does on the device). Returns total count. */
+uint32_t orc_merge_draw_lists(uint32_t n_shards, const OrcDrawCmd* const* lists,
+                              const uint32_t* counts, const uint32_t* index_totals,
+                              OrcDrawCmd* out, uint32_t* out_index_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,182 @@
+"""ctypes binding of oracle/mip_oracle.c (TEST INFRASTRUCTURE ONLY, parity unpinned)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmip_oracle.so")
+
+MAX_LODS = 6
+
+# numpy mirrors of OrcMesh / OrcDrawCmd (= MipMesh / VkDrawIndexedIndirectCommand)
+ORC_MESH_DTYPE = np.dtype(
+    [
+        ("aabb_min", "<f4", (3,)),
+        ("aabb_max", "<f4", (3,)),
+        ("n_lods", "<u4"),
+        ("index_len", "<u4", (MAX_LODS,)),
+        ("index_offset", "<u4", (MAX_LODS,)),
+        ("vertex_offset", "<i4"),
+    ]
+)
+assert ORC_MESH_DTYPE.itemsize == 80
+DRAW_CMD_DTYPE = np.dtype(
+    [
+        ("indexCount", "<u4"),
+        ("instanceCount", "<u4"),
+        ("firstIndex", "<u4"),
+        ("vertexOffset", "<i4"),
+        ("firstInstance", "<u4"),
+    ]
+)
+assert DRAW_CMD_DTYPE.itemsize == 20
+
+
+class _Outputs(C.Structure):
+    _fields_ = [
+        ("model", C.c_void_p),
+        ("world_aabb", C.c_void_p),
+        ("visible_bitmap", C.c_void_p),
+        ("coarse_culled", C.c_void_p),
+        ("draw_cmds", C.c_void_p),
+        ("draw_count", C.c_uint32),
+        ("draw_index_total", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
+    src_newer = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+        for f in ("mip_oracle.c", "mip_oracle.h", "Makefile")
+    )
+    if force or src_newer:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_run.restype = C.c_int
+        _lib.orc_run_mt.restype = C.c_int
+        _lib.orc_coarse_culled.restype = C.c_int
+        _lib.orc_pick_lod.restype = C.c_uint32
+        _lib.orc_compact_draw_stream.restype = C.c_uint32
+        _lib.orc_merge_draw_lists.restype = C.c_uint32
+    return _lib
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def model_matrix(pos, rot_ijkw, scale):
+    m = np.empty(16, np.float32)
+    lib().orc_model_matrix(_p(_f32(pos)), _p(_f32(rot_ijkw)), C.c_float(float(scale)), _p(m))
+    return m
+
+
+def world_aabb(m, mesh_min, mesh_max):
+    mins = np.empty(3, np.float32)
+    maxs = np.empty(3, np.float32)
+    lib().orc_world_aabb(_p(_f32(m)), _p(_f32(mesh_min)), _p(_f32(mesh_max)), _p(mins), _p(maxs))
+    return mins, maxs
+
+
+def coarse_culled(mins, maxs, planes):
+    return bool(lib().orc_coarse_culled(_p(_f32(mins)), _p(_f32(maxs)), _p(_f32(planes, (24,)))))
+
+
+def pick_lod(n_lods, cam_pos, mesh_pos):
+    return int(lib().orc_pick_lod(C.c_uint32(n_lods), _p(_f32(cam_pos)), _p(_f32(mesh_pos))))
+
+
+def project_camera(cam_pos=(0.0, 1.0, 2.0), cam_rot_ijkw=(0.0, 0.0, 0.0, 1.0), aspect=2.0,
+                   fovy_degrees=70.0, near=0.1, far=100.0):
+    """Reference defaults: camera_controller.rs:21, ecs.rs:69-72, instance.rs:45 (2000x1000)."""
+    planes = np.empty(24, np.float32)
+    lib().orc_project_camera(_p(_f32(cam_pos)), _p(_f32(cam_rot_ijkw)), C.c_float(aspect),
+                             C.c_float(fovy_degrees), C.c_float(near), C.c_float(far), _p(planes))
+    return planes
+
+
+def compact_draw_stream(cmds):
+    cmds = np.ascontiguousarray(cmds, dtype=DRAW_CMD_DTYPE)
+    out = np.zeros_like(cmds)
+    n = lib().orc_compact_draw_stream(_p(cmds), C.c_uint32(len(cmds)), _p(out))
+    return out[:n]
+
+
+def merge_draw_lists(lists, index_totals):
+    lists = [np.ascontiguousarray(l, dtype=DRAW_CMD_DTYPE) for l in lists]
+    counts = np.array([len(l) for l in lists], np.uint32)
+    totals = np.ascontiguousarray(index_totals, dtype=np.uint32)
+    ptrs = (C.c_void_p * len(lists))(*[l.ctypes.data for l in lists])
+    out = np.zeros(int(counts.sum()), DRAW_CMD_DTYPE)
+    tot = C.c_uint32(0)
+    n = lib().orc_merge_draw_lists(C.c_uint32(len(lists)), ptrs, _p(counts), _p(totals), _p(out),
+                                   C.byref(tot))
+    return out[:n], int(tot.value)
+
+
+def run(pos_xyz, rot_ijkw, scale, mesh_id, meshes, planes, cam_pos, first_instance_base=0,
+        first_index_base=0, threads=None, want=("model", "world_aabb", "visible_bitmap",
+                                                "coarse_culled", "draw_cmds")):
+    """Whole path. Returns a dict of numpy arrays (+ draw_count, draw_index_total)."""
+    pos_xyz = _f32(pos_xyz).reshape(-1, 3)
+    n = pos_xyz.shape[0]
+    rot_ijkw = _f32(rot_ijkw).reshape(-1, 4)
+    scale = _f32(scale).reshape(-1)
+    mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32).reshape(-1)
+    meshes = np.ascontiguousarray(meshes, dtype=ORC_MESH_DTYPE).reshape(-1)
+    assert rot_ijkw.shape[0] == n and scale.shape[0] == n and mesh_id.shape[0] == n
+    planes = _f32(planes, (24,))
+    cam_pos = _f32(cam_pos, (3,))
+    res = {}
+    o = _Outputs()
+    if "model" in want:
+        res["model"] = np.empty((n, 16), np.float32)
+        o.model = res["model"].ctypes.data
+    if "world_aabb" in want:
+        res["world_aabb"] = np.empty((n, 6), np.float32)
+        o.world_aabb = res["world_aabb"].ctypes.data
+    if "visible_bitmap" in want:
+        res["visible_bitmap"] = np.zeros((n + 31) // 32, np.uint32)
+        o.visible_bitmap = res["visible_bitmap"].ctypes.data
+    if "coarse_culled" in want:
+        res["coarse_culled"] = np.empty(n, np.uint8)
+        o.coarse_culled = res["coarse_culled"].ctypes.data
+    cmds = None
+    if "draw_cmds" in want:
+        cmds = np.zeros(max(n, 1), DRAW_CMD_DTYPE)
+        o.draw_cmds = cmds.ctypes.data
+    args = [C.c_uint32(n), _p(pos_xyz), _p(rot_ijkw), _p(scale), _p(mesh_id), _p(meshes),
+            C.c_uint32(len(meshes)), _p(planes), _p(cam_pos), C.c_uint32(first_instance_base),
+            C.c_uint32(first_index_base), C.byref(o)]
+    if threads is None:
+        rc = lib().orc_run(*args)
+    else:
+        rc = lib().orc_run_mt(*args, C.c_uint32(int(threads)))
+    if rc != 0:
+        raise ValueError("oracle: mesh id out of range or allocation failure")
+    res["draw_count"] = int(o.draw_count)
+    res["draw_index_total"] = int(o.draw_index_total)
+    if cmds is not None:
+        res["draw_cmds"] = cmds[: o.draw_count].copy()
+    return res

@@ -1,0 +1,129 @@
+"""Loads libmi_instance_pipeline.so and declares the C ABI (include/mi_instance_pipeline.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libmi_instance_pipeline.so")
+
+MIP_OK = 0
+ERR_NAMES = {
+    -1: "MIP_ERR_INVALID_ARGUMENT",
+    -2: "MIP_ERR_NO_DEVICE",
+    -3: "MIP_ERR_OUT_OF_MEMORY",
+    -4: "MIP_ERR_CAPACITY",
+    -5: "MIP_ERR_DEVICE",
+    -6: "MIP_ERR_NOT_READY",
+    -7: "MIP_ERR_TIMEOUT",
+}
+MIP_CFG_TIMING = 0x1
+MIP_OUT_HOST = 0x0
+MIP_OUT_DEVICE = 0x1
+MIP_OUT_ASYNC = 0x2
+MIP_MAX_LODS = 6
+
+# Every symbol include/mi_instance_pipeline.h declares.
+EXPORTS = (
+    "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
+    "mip_set_instances_device", "mip_run", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
+    "mip_get_timings", "mip_reset_timings", "mip_instance_count",
+)
+
+
+class MipError(RuntimeError):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+
+
+class MipConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device_ordinal", C.c_int32),
+        ("max_instances", C.c_uint32),
+        ("max_meshes", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class MipFrame(C.Structure):
+    _fields_ = [
+        ("planes", C.c_float * 24),
+        ("cam_pos", C.c_float * 3),
+        ("first_instance_base", C.c_uint32),
+        ("first_index_base", C.c_uint32),
+    ]
+
+
+class MipOutputs(C.Structure):
+    _fields_ = [
+        ("model", C.c_void_p),
+        ("visible_bitmap", C.c_void_p),
+        ("draw_cmds", C.c_void_p),
+        ("draw_count", C.c_void_p),
+        ("draw_index_total", C.c_void_p),
+        ("world_aabb", C.c_void_p),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class MipTimings(C.Structure):
+    _fields_ = [
+        ("runs", C.c_uint64),
+        ("last_kernel_ms", C.c_double),
+        ("total_kernel_ms", C.c_double),
+        ("last_merge_ms", C.c_double),
+        ("total_merge_ms", C.c_double),
+        ("merges", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def load_library():
+    """Returns the ctypes handle. Raises ImportError if the HIP library has not been built —
+    there is deliberately nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C renderer_amd/csrc`. The instance pipeline has no CPU fallback."
+        )
+    lib = C.CDLL(_SO)
+    vp = C.c_void_p
+    lib.mip_abi_version.restype = C.c_uint32
+    lib.mip_create.argtypes = [C.POINTER(MipConfig), C.POINTER(vp)]
+    lib.mip_create.restype = C.c_int32
+    lib.mip_destroy.argtypes = [vp]
+    lib.mip_destroy.restype = None
+    lib.mip_set_mesh_table.argtypes = [vp, vp, C.c_uint32]
+    lib.mip_set_mesh_table.restype = C.c_int32
+    lib.mip_set_instances.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
+    lib.mip_set_instances.restype = C.c_int32
+    lib.mip_set_instances_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
+    lib.mip_set_instances_device.restype = C.c_int32
+    lib.mip_run.argtypes = [vp, C.POINTER(MipFrame), C.POINTER(MipOutputs)]
+    lib.mip_run.restype = C.c_int32
+    lib.mip_wait.argtypes = [vp]
+    lib.mip_wait.restype = C.c_int32
+    lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp, vp, C.c_int32]
+    lib.mip_merge_draw_lists.restype = C.c_int32
+    lib.mip_last_error.argtypes = [vp]
+    lib.mip_last_error.restype = C.c_char_p
+    lib.mip_get_timings.argtypes = [vp, C.POINTER(MipTimings)]
+    lib.mip_get_timings.restype = C.c_int32
+    lib.mip_reset_timings.argtypes = [vp]
+    lib.mip_reset_timings.restype = C.c_int32
+    lib.mip_instance_count.argtypes = [vp]
+    lib.mip_instance_count.restype = C.c_uint32
+    _lib = lib
+    return lib

@@ -1,0 +1,531 @@
+// instance_pipeline_kernels.hpp — gfx950 (CDNA4) kernels of the instance pipeline.
+//
+// One fused, single-pass kernel per frame:
+//
+//   tile = 256 instances = one 256-thread workgroup (4 wave64), one instance per lane
+//   loads   : pos (12 B) + quat (16 B) + scale (4 B) + mesh id (4 B)            = 36 B
+//   compute : M = T·R·S, 8-corner world AABB, 6-plane test, LOD pick             (VALU, no FMA)
+//   stores  : mat4 through an LDS transpose so every store instruction writes
+//             1 KiB contiguous (64 B), 1 visibility bit, and — after a decoupled
+//             look-back over per-tile {count, Σ index_len} granules — the tile's
+//             surviving VkDrawIndexedIndirectCommands, coalesced, in draw_index order.
+//
+// Reference semantics (paths in farnoy/renderer):
+//   src/ecs.rs:52-64 model_matrix_calculation, :138-181 aabb_calculation,
+//   src/renderer/systems/cull_pipeline.rs:99-120 coarse_culling, :534-577 cull_pass,
+//   src/renderer/helpers.rs:3-11 pick_lod, src/shaders/generate_work.comp:61-67,
+//   src/shaders/compact_draw_stream.comp:34-63.
+//
+// Arithmetic contract: IEEE binary32, every multiply and add rounded separately, in
+// the operation order nalgebra 0.29 / ncollide3d 0.32 use. This TU
+// must be compiled with -ffp-contract=off and without fast-math.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace mip {
+
+constexpr uint32_t kTile = 256;           // instances per tile == threads per workgroup
+constexpr uint32_t kWaves = kTile / 64;   // wave64
+constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
+
+// Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
+// len0 = index_len[0]; len1 = index_len[1] if n_lods > 1 else index_len[0]
+// (pick_lod falls back to LOD 0 when there is only one, helpers.rs:6).
+struct alignas(16) MeshEntry {
+  float min_x, min_y, min_z;
+  uint32_t len0;
+  float max_x, max_y, max_z;
+  uint32_t len1;
+};
+
+struct KernelArgs {
+  const float* pos;             // n*3
+  const float4* rot;            // n  [i,j,k,w]
+  const float* scale;           // n
+  const uint32_t* mesh_id;      // n
+  const MeshEntry* meshes;      // m
+  const int32_t* vertex_offset; // m
+  float4* model;                // n*4 or null
+  uint32_t* bitmap;             // ceil(n/32) or null
+  uint32_t* cmds;               // n*5 or null
+  uint32_t* draw_count;         // with cmds
+  uint32_t* index_total;        // optional
+  float* world_aabb;            // n*6 or null
+  unsigned long long* status;   // 2 granules per tile
+  uint32_t* error_flag;         // host-mapped
+  uint32_t n;
+  uint32_t n_tiles;
+  uint32_t epoch;               // 1 .. 2^31-1, unique per launch
+  uint32_t bitmap_words;
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  float planes[24];
+  float cam[3];
+};
+
+// Largest q with sqrt_rn(q) <= 10: pick_lod tests `magnitude() > 10.0`
+// (helpers.rs:4-6) and magnitude = sqrt(norm_squared) correctly rounded, so
+// sqrt_rn(q) > 10  <=>  q > nextafter(100) (tests/test_oracle.py checks this
+// equivalence exhaustively around 100).
+constexpr float kLodDistSqThreshold = 100.00000762939453125f;  // 100 + 2^-17
+
+constexpr uint32_t kErrTimeout = 1u;
+
+// ---------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------
+
+// Inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (gfx9).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---------------------------------------------------------------------------------------
+// per-instance arithmetic
+// ---------------------------------------------------------------------------------------
+
+struct Instance {
+  float m[12];      // rows 0..2 of the model matrix, column-major: m[c*3 + r]
+  uint32_t row3;    // bit c set <=> M[3][c] is NaN (otherwise it is 0,0,0,1)
+  float mins[3], maxs[3];
+};
+
+// nalgebra UnitQuaternion::to_rotation_matrix; r[row][col].
+__device__ __forceinline__ void quat_to_rotation(float i, float j, float k, float w, float (&r)[3][3]) {
+  const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+  const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+  const float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+  r[0][0] = ww + ii - jj - kk; r[0][1] = ij - wk;           r[0][2] = wj + ik;
+  r[1][0] = wk + ij;           r[1][1] = ww - ii + jj - kk; r[1][2] = jk - wi;
+  r[2][0] = ik - wj;           r[2][1] = wi + jk;           r[2][2] = ww - ii - jj + kk;
+}
+
+__device__ __forceinline__ void fold_corner(const float (&v)[3], float (&lo)[3], float (&hi)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = fminf(lo[a], v[a]);  // f32::min: a NaN operand is ignored
+    hi[a] = fmaxf(hi[a], v[a]);
+  }
+}
+
+__device__ __forceinline__ void finish_aabb(const float (&lo)[3], const float (&hi)[3], Instance& o) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float centre = (hi[a] + lo[a]) / 2.0f;
+    const float half = (hi[a] - lo[a]) / 2.0f;
+    o.mins[a] = centre - half;  // AABB::from_half_extents
+    o.maxs[a] = centre + half;
+  }
+}
+
+// Fast path, exact whenever the 9 rotation entries, the position and the scale are all
+// finite (and the mesh box is, which mip_set_mesh_table enforces): then every product
+// with a 0 or 1 entry of T, S and the homogeneous row/column is exact, (T·R)·S collapses
+// to M[r][c] = fl(R[r][c]·s), M[:,3] = (p,1), M[3,:] = (0,0,0,1), and w = 1 for every
+// corner, so `/ w` is the identity.
+__device__ __forceinline__ void instance_fast(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) o.m[c * 3 + rr] = r[rr][c] * s;
+  o.m[9] = px; o.m[10] = py; o.m[11] = pz;
+  o.row3 = 0;
+  float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+  const float bx[2] = {mb.min_x, mb.max_x}, by[2] = {mb.min_y, mb.max_y}, bz[2] = {mb.min_z, mb.max_z};
+  // corner order of src/ecs.rs:149-160: x toggles fastest, then z, then y
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float x = bx[c & 1], z = bz[(c >> 1) & 1], y = by[(c >> 2) & 1];
+    float v[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)  // gemv as column axpys: ((m0 x + m1 y) + m2 z) + m3·1
+      v[rr] = o.m[0 * 3 + rr] * x + o.m[1 * 3 + rr] * y + o.m[2 * 3 + rr] * z + o.m[9 + rr];
+    fold_corner(v, lo, hi);
+  }
+  finish_aabb(lo, hi, o);
+}
+
+// nalgebra gemv (alpha = 1, beta = 0): column axpys left to right.
+__device__ __forceinline__ void gemv4(const float (&a)[16], const float (&x)[4], float (&y)[4]) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) y[rr] = a[rr] * x[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) y[rr] = a[k * 4 + rr] * x[k] + y[rr];
+}
+
+__device__ __forceinline__ void gemm4(const float (&a)[16], const float (&b)[16], float (&out)[16]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float x[4] = {b[c * 4 + 0], b[c * 4 + 1], b[c * 4 + 2], b[c * 4 + 3]};
+    float y[4];
+    gemv4(a, x, y);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) out[c * 4 + rr] = y[rr];
+  }
+}
+
+// General path: the reference chain performed literally — translation(p) *
+// rot.to_homogeneous() * scaling(s) as two full 4x4 products, full mat4*vec4 per corner
+// and the divide by w — so non-finite inputs poison exactly the entries they poison in
+// the reference. Taken by a whole wave when any of its lanes fails the finite test.
+__device__ __forceinline__ void instance_general(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+  float t[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, px, py, pz, 1};
+  float rh[16] = {r[0][0], r[1][0], r[2][0], 0, r[0][1], r[1][1], r[2][1], 0,
+                  r[0][2], r[1][2], r[2][2], 0, 0, 0, 0, 1};
+  float sc[16] = {s, 0, 0, 0, 0, s, 0, 0, 0, 0, s, 0, 0, 0, 0, 1};
+  float tr[16], m[16];
+  gemm4(t, rh, tr);
+  gemm4(tr, sc, m);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) o.m[c * 3 + rr] = m[c * 4 + rr];
+  o.row3 = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o.row3 |= (m[c * 4 + 3] != m[c * 4 + 3]) ? (1u << c) : 0u;
+  float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {  // unrolled so the corner selects stay in registers
+    const float vh[4] = {(c & 1) ? mb.max_x : mb.min_x, (c & 4) ? mb.max_y : mb.min_y,
+                         (c & 2) ? mb.max_z : mb.min_z, 1.0f};
+    float tv[4];
+    gemv4(m, vh, tv);
+    const float v[3] = {tv[0] / tv[3], tv[1] / tv[3], tv[2] / tv[3]};
+    fold_corner(v, lo, hi);
+  }
+  finish_aabb(lo, hi, o);
+}
+
+// src/renderer/systems/cull_pipeline.rs:108-119. Planes are wave-uniform (SGPRs).
+__device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&planes)[24]) {
+  float h[3], c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    h[a] = (o.maxs[a] - o.mins[a]) * 0.5f;  // AABB::half_extents
+    c[a] = (o.mins[a] + o.maxs[a]) * 0.5f;  // AABB::center
+  }
+  bool outside = false;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const float nx = planes[p * 4 + 0], ny = planes[p * 4 + 1], nz = planes[p * 4 + 2], d = planes[p * 4 + 3];
+    const float e = h[0] * fabsf(nx) + h[1] * fabsf(ny) + h[2] * fabsf(nz);  // 3-wide dot: (a+b)+c
+    float a0 = nx * c[0];
+    float a1 = ny * c[1];
+    const float a2 = nz * c[2];
+    const float a3 = d;  // d * 1
+    a0 += a2;            // 4-wide dot: (a0+a2) + (a1+a3)
+    a1 += a3;
+    const float sd = a0 + a1;
+    outside = outside || (sd - e > 0.0f);  // the reference's early break changes nothing
+  }
+  return outside;
+}
+
+// ---------------------------------------------------------------------------------------
+// tile status granules (decoupled look-back)
+// ---------------------------------------------------------------------------------------
+// Two 8-byte granules per tile, each written by ONE relaxed agent-scope atomic store
+// (global_store_dwordx2 sc1) and read by relaxed agent-scope atomic loads:
+//   granule 0 = { tag, count }   granule 1 = { tag, Σ index_len }
+//   tag = epoch << 1 | is_inclusive_prefix
+// The epoch changes every launch, so the array is never cleared; a reader accepts a
+// tile only when both granules carry the same tag of the current epoch. No payload is
+// handed off behind these words, so no release/acquire fence is involved.
+
+__device__ __forceinline__ void status_store(unsigned long long* p, uint32_t tag, uint32_t value) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ unsigned long long status_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz realtime counter
+
+// Run by wave 0 of the workgroup. Returns the exclusive prefix (count, Σ index_len) of `tile`.
+__device__ __forceinline__ void look_back(const KernelArgs& a, uint32_t tile, uint32_t lane,
+                                          uint32_t& base_count, uint32_t& base_sum) {
+  uint32_t excl_c = 0, excl_s = 0;
+  int32_t base = (int32_t)tile - 1;
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  bool give_up = false;
+  while (base >= 0 && !give_up) {
+    const int32_t idx = base - (int32_t)lane;  // lane 0 looks at the nearest predecessor
+    const bool valid = idx >= 0;
+    bool ready = !valid, is_prefix = false;
+    uint32_t c = 0, s = 0;
+    for (;;) {
+      if (!ready) {
+        const unsigned long long g0 = status_load(&a.status[2 * (size_t)idx]);
+        const unsigned long long g1 = status_load(&a.status[2 * (size_t)idx + 1]);
+        const uint32_t t0 = (uint32_t)(g0 >> 32), t1 = (uint32_t)(g1 >> 32);
+        if ((t0 >> 1) == a.epoch && t0 == t1) {
+          ready = true;
+          is_prefix = (t0 & 1u) != 0;
+          c = (uint32_t)g0;
+          s = (uint32_t)g1;
+        }
+      }
+      if (__all(ready)) break;
+      if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {
+        give_up = true;  // wave-uniform: s_memrealtime is scalar
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (give_up) break;
+    const unsigned long long pmask = __ballot(valid && is_prefix);
+    const uint32_t last = pmask ? (uint32_t)__builtin_ctzll(pmask) : 63u;  // nearest tile holding a prefix
+    const bool take = valid && lane <= last;
+    excl_c += wave_sum(take ? c : 0u);
+    excl_s += wave_sum(take ? s : 0u);
+    if (pmask) break;
+    base -= 64;
+  }
+  if (give_up && lane == 0) atomicOr(a.error_flag, kErrTimeout);
+  base_count = excl_c;
+  base_sum = excl_s;
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
+  __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
+  __shared__ __attribute__((aligned(16))) uint32_t s_cmd[kTile * kCmdWords];
+  __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
+  __shared__ uint32_t s_base[2];
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tile_first = tile * kTile;
+  const uint32_t i = tile_first + tid;
+  const bool active = i < a.n;
+  const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
+
+  // ---- loads: 36 B per instance ----
+  const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
+  const float4 q = a.rot[il];
+  const float sc = a.scale[il];
+  const uint32_t mesh = a.mesh_id[il];
+  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
+  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  MeshEntry mb;
+  mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
+  mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
+
+  // ---- model matrix + world AABB ----
+  float r[3][3];
+  quat_to_rotation(q.x, q.y, q.z, q.w, r);
+  // Finite test for the fast path: a sum of magnitudes is NaN/inf as soon as one term is
+  // (or the sum overflows — then the general path, which is exact for everything, runs).
+  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  const bool all_finite = mag < 3.0e38f;
+  Instance inst;
+  if (__builtin_expect(__any(!all_finite), 0)) {
+    instance_general(r, px, py, pz, sc, mb, inst);
+  } else {
+    instance_fast(r, px, py, pz, sc, mb, inst);
+  }
+
+  // ---- frustum test, LOD, command length ----
+  const bool culled = coarse_culled(inst, a.planes);
+  const bool visible = active && !culled;
+  const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
+  const float dist_sq = dx * dx + dy * dy + dz * dz;
+  const uint32_t len = (dist_sq > kLodDistSqThreshold) ? mb.len1 : mb.len0;
+  const bool keep = visible && len > 0u;  // compact_draw_stream.comp:41 `indexCount > 0`
+  const uint32_t len_vis = visible ? len : 0u;
+
+  // ---- wave-level compaction offsets ----
+  const unsigned long long keep_mask = __ballot(keep);
+  const unsigned long long vis_mask = __ballot(visible);
+  const uint32_t rank_in_wave = lanes_below(keep_mask);
+  const uint32_t incl_sum = wave_inclusive_scan(len_vis);
+  if (lane == 63u) {
+    s_wave_count[wave] = (uint32_t)__popcll(keep_mask);
+    s_wave_sum[wave] = incl_sum;
+  }
+
+  // ---- stage the matrix rows for the transposed store ----
+  if (a.model) {
+    float4* dst = reinterpret_cast<float4*>(&s_mat[tid * 12]);
+    dst[0] = make_float4(inst.m[0], inst.m[1], inst.m[2], inst.m[3]);
+    dst[1] = make_float4(inst.m[4], inst.m[5], inst.m[6], inst.m[7]);
+    dst[2] = make_float4(inst.m[8], inst.m[9], inst.m[10], inst.m[11]);
+    s_row3[tid] = inst.row3;
+  }
+  __syncthreads();
+
+  uint32_t wave_off_count = 0, wave_off_sum = 0, tile_count = 0, tile_sum = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kWaves; ++w) {
+    const uint32_t wc = s_wave_count[w], ws = s_wave_sum[w];
+    if (w < wave) { wave_off_count += wc; wave_off_sum += ws; }
+    tile_count += wc;
+    tile_sum += ws;
+  }
+
+  const bool want_cmds = a.cmds != nullptr;
+  const uint32_t tag_aggregate = a.epoch << 1, tag_prefix = tag_aggregate | 1u;
+  if (want_cmds && tid == 0) {
+    // tile 0 has no predecessor: its aggregate is already its inclusive prefix
+    const uint32_t tag = tile == 0 ? tag_prefix : tag_aggregate;
+    status_store(&a.status[2 * (size_t)tile], tag, tile_count);
+    status_store(&a.status[2 * (size_t)tile + 1], tag, tile_sum);
+  }
+
+  // ---- model matrices: 4 store instructions per wave, each 1 KiB contiguous ----
+  if (a.model) {
+    const uint32_t wave_first = wave * 64u;
+    const float* src = &s_mat[wave_first * 12];
+    float4* out = a.model + ((size_t)tile_first + wave_first) * 4;
+    const uint32_t col = lane & 3u;
+#pragma unroll
+    for (uint32_t s4 = 0; s4 < 4; ++s4) {
+      const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
+      const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
+      const uint32_t bits = s_row3[wave_first + local];
+      float w = (col == 3u) ? 1.0f : 0.0f;
+      if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
+      if (tile_first + wave_first + local < a.n)
+        out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
+    }
+  }
+
+  // ---- visibility bitmap: one 64-bit ballot per wave, written as two words ----
+  if (a.bitmap && lane < 2u) {
+    const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
+    if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
+  }
+
+  // ---- optional world AABB (mins, maxs) as the ECS component holds it ----
+  if (a.world_aabb && active) {
+    float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
+    o2[0] = make_float2(inst.mins[0], inst.mins[1]);
+    o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
+    o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
+  }
+
+  if (!want_cmds) return;
+
+  // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
+  if (keep) {
+    uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdWords];
+    c[0] = len;                                               // indexCount
+    c[1] = 1u;                                                // instanceCount, generate_work.comp:63
+    c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
+    c[3] = (uint32_t)a.vertex_offset[mesh];                   // vertexOffset, :66
+    c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
+  }
+
+  // ---- decoupled look-back (wave 0), then publish the inclusive prefix ----
+  if (wave == 0) {
+    uint32_t base_count = 0, base_sum = 0;
+    if (tile > 0) {
+      look_back(a, tile, lane, base_count, base_sum);
+      if (lane == 0) {
+        status_store(&a.status[2 * (size_t)tile], tag_prefix, base_count + tile_count);
+        status_store(&a.status[2 * (size_t)tile + 1], tag_prefix, base_sum + tile_sum);
+      }
+    }
+    if (lane == 0) {
+      s_base[0] = base_count;
+      s_base[1] = base_sum;
+      if (tile == a.n_tiles - 1u) {
+        *a.draw_count = base_count + tile_count;
+        if (a.index_total) *a.index_total = base_sum + tile_sum;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- coalesced copy-out of the tile's commands ----
+  const uint32_t base_count = s_base[0];
+  const uint32_t first_index_add = s_base[1] + a.first_index_base;
+  uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
+  const uint32_t words = tile_count * kCmdWords;
+  for (uint32_t j = tid; j < words; j += kTile) {
+    uint32_t v = s_cmd[j];
+    if (j % kCmdWords == 2u) v += first_index_add;
+    out[j] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// shard merge (multi-GPU): concatenate all-gathered chunks, rebasing firstIndex
+// ---------------------------------------------------------------------------------------
+
+struct MergeArgs {
+  const unsigned char* chunks;
+  unsigned long long stride;
+  uint32_t n_chunks;
+  uint32_t* out_cmds;
+  uint32_t* out_count;  // [0] = commands, [1] = indices
+};
+
+constexpr uint32_t kMaxMergeChunks = 64;
+
+__global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeArgs a) {
+  __shared__ uint32_t s_count_base[kMaxMergeChunks + 1], s_index_base[kMaxMergeChunks + 1];
+  if (threadIdx.x == 0) {
+    uint32_t c = 0, s = 0;
+    for (uint32_t k = 0; k < a.n_chunks; ++k) {
+      const uint32_t* h = reinterpret_cast<const uint32_t*>(a.chunks + k * a.stride);
+      s_count_base[k] = c;
+      s_index_base[k] = s;
+      c += h[0];
+      s += h[1];
+    }
+    s_count_base[a.n_chunks] = c;
+    s_index_base[a.n_chunks] = s;
+    if (blockIdx.x == 0) {
+      a.out_count[0] = c;
+      a.out_count[1] = s;
+    }
+  }
+  __syncthreads();
+  const uint32_t total_words = s_count_base[a.n_chunks] * kCmdWords;
+  const uint32_t stride_threads = gridDim.x * blockDim.x;
+  uint32_t chunk = 0;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total_words; j += stride_threads) {
+    const uint32_t cmd = j / kCmdWords, field = j - cmd * kCmdWords;
+    while (cmd >= s_count_base[chunk + 1]) ++chunk;  // j only grows
+    const uint32_t* body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32);
+    uint32_t v = body[(cmd - s_count_base[chunk]) * kCmdWords + field];
+    if (field == 2u) v += s_index_base[chunk];
+    a.out_cmds[j] = v;
+  }
+}
+
+}  // namespace mip

@@ -1,0 +1,411 @@
+// mip_api.hip — C ABI of the instance pipeline (include/mi_instance_pipeline.h) over the
+// gfx950 kernels in instance_pipeline_kernels.hpp. HIP runtime only: no torch types, no
+// CPU fallback. Modelled on the reference's one FFI precedent, the vma crate
+// (vma/src/lib.rs:31-64; status-code returns as in src/renderer/device/alloc.rs:192-226).
+#include "../../include/mi_instance_pipeline.h"
+#include "instance_pipeline_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static_assert(sizeof(MipDrawIndexedIndirectCommand) == 20, "VkDrawIndexedIndirectCommand is 20 bytes");
+static_assert(sizeof(MipMesh) == 80, "MipMesh layout");
+static_assert(sizeof(MipShardHeader) == 32, "MipShardHeader layout");
+static_assert(sizeof(mip::MeshEntry) == 32, "MeshEntry layout");
+static_assert(sizeof(mip::KernelArgs) <= 4096, "kernel argument block");
+
+struct MipContext {
+  int device = -1;
+  uint32_t max_instances = 0, max_meshes = 0, cfg_flags = 0;
+  uint32_t n = 0, m = 0;
+  bool have_instances = false, have_meshes = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // resident inputs
+  float* d_pos = nullptr;
+  float4* d_rot = nullptr;
+  float* d_scale = nullptr;
+  uint32_t* d_mesh_id = nullptr;
+  mip::MeshEntry* d_meshes = nullptr;
+  int32_t* d_vertex_offset = nullptr;
+  // look-back state
+  unsigned long long* d_status = nullptr;
+  uint32_t epoch = 0;
+  uint32_t* h_error = nullptr;  // pinned, device-visible
+  uint32_t* d_error = nullptr;  // device alias of h_error
+  uint32_t* d_scalars = nullptr;  // [0] draw_count, [1] index_total, [2..3] merge out
+  // staging for MIP_OUT_HOST
+  float4* s_model = nullptr;
+  uint32_t* s_bitmap = nullptr;
+  uint32_t* s_cmds = nullptr;
+  float* s_aabb = nullptr;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  MipTimings timings{};
+  bool pending_async = false;
+  char err[512] = {0};
+};
+
+namespace {
+
+int32_t fail(MipContext* ctx, int32_t code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define MIP_HIP(ctx, call)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? MIP_ERR_OUT_OF_MEMORY : MIP_ERR_DEVICE,     \
+                  "%s failed: %s", #call, hipGetErrorString(e_));                             \
+  } while (0)
+
+uint32_t tiles_for(uint32_t n) { return (n + mip::kTile - 1) / mip::kTile; }
+
+int32_t bind_device(MipContext* ctx) {
+  MIP_HIP(ctx, hipSetDevice(ctx->device));
+  return MIP_OK;
+}
+
+int32_t ensure_staging(MipContext* ctx, const MipOutputs* out) {
+  const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
+  if (out->model && !ctx->s_model) MIP_HIP(ctx, hipMalloc(&ctx->s_model, cap * 64));
+  if (out->visible_bitmap && !ctx->s_bitmap) MIP_HIP(ctx, hipMalloc(&ctx->s_bitmap, ((cap + 31) / 32) * 4));
+  if (out->draw_cmds && !ctx->s_cmds) MIP_HIP(ctx, hipMalloc(&ctx->s_cmds, cap * 20));
+  if (out->world_aabb && !ctx->s_aabb) MIP_HIP(ctx, hipMalloc(&ctx->s_aabb, cap * 24));
+  return MIP_OK;
+}
+
+// Reads and clears the device-visible error word after the stream has drained.
+int32_t check_device_error(MipContext* ctx) {
+  const uint32_t e = *(volatile uint32_t*)ctx->h_error;
+  if (e) {
+    *(volatile uint32_t*)ctx->h_error = 0;
+    return fail(ctx, MIP_ERR_TIMEOUT,
+                "look-back wait expired (a predecessor tile never published); outputs invalid");
+  }
+  return MIP_OK;
+}
+
+void free_all(MipContext* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->d_pos);
+  (void)hipFree(ctx->d_rot);
+  (void)hipFree(ctx->d_scale);
+  (void)hipFree(ctx->d_mesh_id);
+  (void)hipFree(ctx->d_meshes);
+  (void)hipFree(ctx->d_vertex_offset);
+  (void)hipFree(ctx->d_status);
+  (void)hipFree(ctx->d_scalars);
+  (void)hipFree(ctx->s_model);
+  (void)hipFree(ctx->s_bitmap);
+  (void)hipFree(ctx->s_cmds);
+  (void)hipFree(ctx->s_aabb);
+  if (ctx->h_error) (void)hipHostFree(ctx->h_error);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mip_abi_version(void) { return MIP_ABI_VERSION; }
+
+int32_t mip_create(const MipConfig* cfg, MipContext** out) {
+  if (out) *out = nullptr;
+  if (!cfg || !out || cfg->struct_size != sizeof(MipConfig)) return MIP_ERR_INVALID_ARGUMENT;
+  if (cfg->max_instances > 0x3fffffffu) return MIP_ERR_INVALID_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MIP_ERR_NO_DEVICE;
+  if (cfg->device_ordinal < 0 || cfg->device_ordinal >= count) return MIP_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device_ordinal) != hipSuccess) return MIP_ERR_NO_DEVICE;
+  // The code object is built for gfx950 only; anything else could not launch it.
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MIP_ERR_NO_DEVICE;
+
+  MipContext* ctx = new (std::nothrow) MipContext();
+  if (!ctx) return MIP_ERR_OUT_OF_MEMORY;
+  ctx->device = cfg->device_ordinal;
+  ctx->max_instances = cfg->max_instances;
+  ctx->max_meshes = cfg->max_meshes;
+  ctx->cfg_flags = cfg->flags;
+
+  int32_t rc = [&]() -> int32_t {
+    MIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (cfg->stream) {
+      ctx->stream = (hipStream_t)cfg->stream;
+    } else {
+      MIP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
+    const size_t mcap = ctx->max_meshes ? ctx->max_meshes : 1;
+    MIP_HIP(ctx, hipMalloc(&ctx->d_pos, cap * 12));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_rot, cap * 16));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_scale, cap * 4));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_id, cap * 4));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_meshes, mcap * sizeof(mip::MeshEntry)));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_vertex_offset, mcap * 4));
+    const size_t status_bytes = (size_t)tiles_for((uint32_t)cap) * 16;
+    MIP_HIP(ctx, hipMalloc(&ctx->d_status, status_bytes));
+    MIP_HIP(ctx, hipMemset(ctx->d_status, 0, status_bytes));  // epoch 0 is never used
+    MIP_HIP(ctx, hipMalloc(&ctx->d_scalars, 64));
+    MIP_HIP(ctx, hipMemset(ctx->d_scalars, 0, 64));
+    MIP_HIP(ctx, hipHostMalloc(&ctx->h_error, 64, hipHostMallocMapped));
+    std::memset(ctx->h_error, 0, 64);
+    MIP_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_error, ctx->h_error, 0));
+    MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
+    MIP_HIP(ctx, hipEventCreate(&ctx->ev1));
+    return MIP_OK;
+  }();
+  if (rc != MIP_OK) {
+    free_all(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return MIP_OK;
+}
+
+void mip_destroy(MipContext* ctx) { free_all(ctx); }
+
+int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!meshes && m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "meshes is NULL");
+  if (m > ctx->max_meshes) return fail(ctx, MIP_ERR_CAPACITY, "%u meshes > max_meshes %u", m, ctx->max_meshes);
+  std::vector<mip::MeshEntry> entries(m);
+  std::vector<int32_t> voff(m);
+  for (uint32_t k = 0; k < m; ++k) {
+    const MipMesh& s = meshes[k];
+    if (s.n_lods < 1 || s.n_lods > MIP_MAX_LODS)
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mesh %u: n_lods %u outside 1..%u", k, s.n_lods, MIP_MAX_LODS);
+    for (int a = 0; a < 3; ++a)
+      if (!std::isfinite(s.aabb_min[a]) || !std::isfinite(s.aabb_max[a]))
+        return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mesh %u: non-finite bounds", k);
+    mip::MeshEntry& e = entries[k];
+    e.min_x = s.aabb_min[0]; e.min_y = s.aabb_min[1]; e.min_z = s.aabb_min[2];
+    e.max_x = s.aabb_max[0]; e.max_y = s.aabb_max[1]; e.max_z = s.aabb_max[2];
+    e.len0 = s.index_len[0];
+    e.len1 = s.n_lods > 1 ? s.index_len[1] : s.index_len[0];
+    voff[k] = s.vertex_offset;
+  }
+  if (int32_t rc = bind_device(ctx)) return rc;
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (m) {
+    MIP_HIP(ctx, hipMemcpy(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice));
+    MIP_HIP(ctx, hipMemcpy(ctx->d_vertex_offset, voff.data(), m * 4, hipMemcpyHostToDevice));
+  }
+  ctx->m = m;
+  ctx->have_meshes = true;
+  return MIP_OK;
+}
+
+static int32_t set_instances_common(MipContext* ctx, const void* pos, const void* rot, const void* scale,
+                                    const void* mesh_id, uint32_t n, hipMemcpyKind kind) {
+  if (n > ctx->max_instances)
+    return fail(ctx, MIP_ERR_CAPACITY, "%u instances > max_instances %u", n, ctx->max_instances);
+  if (n && (!pos || !rot || !scale || !mesh_id)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL instance column");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n) {
+    MIP_HIP(ctx, hipMemcpy(ctx->d_pos, pos, (size_t)n * 12, kind));
+    MIP_HIP(ctx, hipMemcpy(ctx->d_rot, rot, (size_t)n * 16, kind));
+    MIP_HIP(ctx, hipMemcpy(ctx->d_scale, scale, (size_t)n * 4, kind));
+    MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind));
+  }
+  ctx->n = n;
+  ctx->have_instances = true;
+  return MIP_OK;
+}
+
+int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* rot_ijkw, const float* scale,
+                          const uint32_t* mesh_id, uint32_t n) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "set the mesh table before the instances");
+  if (n && mesh_id)
+    for (uint32_t i = 0; i < n; ++i)
+      if (mesh_id[i] >= ctx->m)
+        return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "instance %u: mesh id %u >= %u meshes", i, mesh_id[i], ctx->m);
+  return set_instances_common(ctx, pos_xyz, rot_ijkw, scale, mesh_id, n, hipMemcpyHostToDevice);
+}
+
+int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw, const void* scale,
+                                 const void* mesh_id, uint32_t n) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "set the mesh table before the instances");
+  return set_instances_common(ctx, pos_xyz, rot_ijkw, scale, mesh_id, n, hipMemcpyDeviceToDevice);
+}
+
+int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!frame || !out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out is NULL");
+  if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
+  if ((out->draw_cmds == nullptr) != (out->draw_count == nullptr))
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_cmds and draw_count go together");
+  if (out->draw_index_total && !out->draw_cmds)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_index_total needs draw_cmds");
+  const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
+  const bool async = device_out && (out->flags & MIP_OUT_ASYNC) != 0;
+  if ((out->flags & MIP_OUT_ASYNC) && !device_out)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
+  if (int32_t rc = bind_device(ctx)) return rc;
+
+  const uint32_t n = ctx->n;
+  const uint32_t words = (n + 31u) / 32u;
+  if (!device_out)
+    if (int32_t rc = ensure_staging(ctx, out)) return rc;
+
+  mip::KernelArgs a{};
+  a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
+  a.meshes = ctx->d_meshes; a.vertex_offset = ctx->d_vertex_offset;
+  a.model = out->model ? (device_out ? (float4*)out->model : ctx->s_model) : nullptr;
+  a.bitmap = out->visible_bitmap ? (device_out ? out->visible_bitmap : ctx->s_bitmap) : nullptr;
+  a.cmds = out->draw_cmds ? (device_out ? (uint32_t*)out->draw_cmds : ctx->s_cmds) : nullptr;
+  a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : ctx->d_scalars + 0) : nullptr;
+  a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : ctx->d_scalars + 1) : nullptr;
+  a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
+  a.status = ctx->d_status;
+  a.error_flag = ctx->d_error;
+  a.n = n;
+  a.n_tiles = tiles_for(n);
+  a.bitmap_words = words;
+  a.first_instance_base = frame->first_instance_base;
+  a.first_index_base = frame->first_index_base;
+  std::memcpy(a.planes, frame->planes, sizeof a.planes);
+  std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
+
+  // A fresh epoch per launch stands in for clearing the tile-status array. On wrap
+  // (every 2^31-2 launches) clear it once and start over.
+  if (ctx->epoch >= 0x7ffffffeu) {
+    MIP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, (size_t)tiles_for(ctx->max_instances ? ctx->max_instances : 1) * 16, ctx->stream));
+    ctx->epoch = 0;
+  }
+  a.epoch = ++ctx->epoch;
+
+  const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0;
+  if (n == 0) {
+    if (a.draw_count) MIP_HIP(ctx, hipMemsetAsync(a.draw_count, 0, 4, ctx->stream));
+    if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, ctx->stream));
+  } else {
+    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), 0, ctx->stream, a);
+    MIP_HIP(ctx, hipGetLastError());
+    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  }
+
+  if (!device_out) {
+    if (n) {
+      if (out->model) MIP_HIP(ctx, hipMemcpyAsync(out->model, ctx->s_model, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->visible_bitmap) MIP_HIP(ctx, hipMemcpyAsync(out->visible_bitmap, ctx->s_bitmap, (size_t)words * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->world_aabb) MIP_HIP(ctx, hipMemcpyAsync(out->world_aabb, ctx->s_aabb, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    uint32_t scalars[2] = {0, 0};
+    if (out->draw_cmds) {
+      MIP_HIP(ctx, hipMemcpyAsync(scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+      MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (scalars[0] > n) return fail(ctx, MIP_ERR_DEVICE, "draw_count %u > n %u", scalars[0], n);
+      if (scalars[0])
+        MIP_HIP(ctx, hipMemcpyAsync(out->draw_cmds, ctx->s_cmds, (size_t)scalars[0] * 20, hipMemcpyDeviceToHost, ctx->stream));
+      *out->draw_count = scalars[0];
+      if (out->draw_index_total) *out->draw_index_total = scalars[1];
+    }
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else if (!async) {
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+
+  if (async) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  if (timing && n) {
+    float ms = 0.f;
+    MIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->timings.runs += 1;
+    ctx->timings.last_kernel_ms = ms;
+    ctx->timings.total_kernel_ms += ms;
+  }
+  return check_device_error(ctx);
+}
+
+int32_t mip_wait(MipContext* ctx) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (int32_t rc = bind_device(ctx)) return rc;
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pending_async = false;
+  return check_device_error(ctx);
+}
+
+int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                             void* out_cmds, uint32_t* out_count, int32_t async) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!chunks || !out_cmds || !out_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (n_chunks == 0 || n_chunks > mip::kMaxMergeChunks)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_chunks %u outside 1..%u", n_chunks, mip::kMaxMergeChunks);
+  if (chunk_stride_bytes < sizeof(MipShardHeader) || (chunk_stride_bytes & 3u))
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad chunk stride");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  mip::MergeArgs a{};
+  a.chunks = (const unsigned char*)chunks;
+  a.stride = chunk_stride_bytes;
+  a.n_chunks = n_chunks;
+  a.out_cmds = (uint32_t*)out_cmds;
+  a.out_count = out_count;
+  const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0 && !async;
+  if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  // Sized for the payload the stride can hold: every thread moves ~8 words.
+  const uint64_t max_words = (chunk_stride_bytes - sizeof(MipShardHeader)) / 4 * n_chunks;
+  uint32_t blocks = (uint32_t)((max_words + 256 * 8 - 1) / (256 * 8));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(mip::mip_merge_draw_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+  MIP_HIP(ctx, hipGetLastError());
+  if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (async) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (timing) {
+    float ms = 0.f;
+    MIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->timings.merges += 1;
+    ctx->timings.last_merge_ms = ms;
+    ctx->timings.total_merge_ms += ms;
+  }
+  return MIP_OK;
+}
+
+const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t mip_get_timings(MipContext* ctx, MipTimings* out) {
+  if (!ctx || !out) return MIP_ERR_INVALID_ARGUMENT;
+  *out = ctx->timings;
+  return MIP_OK;
+}
+
+int32_t mip_reset_timings(MipContext* ctx) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  ctx->timings = MipTimings{};
+  return MIP_OK;
+}
+
+uint32_t mip_instance_count(const MipContext* ctx) { return ctx ? ctx->n : 0; }
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""ctypes host wrapper over the C ABI. Mirrors the order the reference's schedule runs the
+path in (src/main.rs:780-839 RenderSetup, then cull_pass): upload the ECS columns once,
+then one `run` per frame."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MipConfig, MipError, MipFrame, MipOutputs, MipTimings
+
+MESH_DTYPE = np.dtype(
+    [
+        ("aabb_min", "<f4", (3,)),
+        ("aabb_max", "<f4", (3,)),
+        ("n_lods", "<u4"),
+        ("index_len", "<u4", (_lib.MIP_MAX_LODS,)),
+        ("index_offset", "<u4", (_lib.MIP_MAX_LODS,)),
+        ("vertex_offset", "<i4"),
+    ]
+)
+DRAW_CMD_DTYPE = np.dtype(
+    [
+        ("indexCount", "<u4"),
+        ("instanceCount", "<u4"),
+        ("firstIndex", "<u4"),
+        ("vertexOffset", "<i4"),
+        ("firstInstance", "<u4"),
+    ]
+)
+SHARD_HEADER_BYTES = 32
+
+
+def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0):
+    f = MipFrame()
+    planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(24)
+    cam_pos = np.ascontiguousarray(cam_pos, dtype=np.float32).reshape(3)
+    f.planes[:] = planes.tolist()
+    f.cam_pos[:] = cam_pos.tolist()
+    f.first_instance_base = int(first_instance_base) & 0xFFFFFFFF
+    f.first_index_base = int(first_index_base) & 0xFFFFFFFF
+    return f
+
+
+class InstancePipeline:
+    """One context on one GPU (one per rank)."""
+
+    def __init__(self, max_instances, max_meshes, device=0, timing=False, stream=None):
+        self._lib = _lib.load_library()
+        self._ctx = C.c_void_p()
+        cfg = MipConfig()
+        cfg.struct_size = C.sizeof(MipConfig)
+        cfg.device_ordinal = int(device)
+        cfg.max_instances = int(max_instances)
+        cfg.max_meshes = int(max_meshes)
+        cfg.flags = _lib.MIP_CFG_TIMING if timing else 0
+        cfg.stream = stream
+        rc = self._lib.mip_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise MipError(rc, "mip_create failed (is there a gfx950 GPU?)")
+        self.max_instances = int(max_instances)
+        self.n = 0
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.mip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.mip_last_error(self._ctx)
+            raise MipError(rc, msg.decode() if msg else "")
+
+    # -- uploads --
+    def set_mesh_table(self, meshes):
+        meshes = np.ascontiguousarray(meshes, dtype=MESH_DTYPE).reshape(-1)
+        self._check(self._lib.mip_set_mesh_table(self._ctx, meshes.ctypes.data, len(meshes)))
+
+    def set_instances(self, pos_xyz, rot_ijkw, scale, mesh_id):
+        pos = np.ascontiguousarray(pos_xyz, dtype=np.float32).reshape(-1, 3)
+        rot = np.ascontiguousarray(rot_ijkw, dtype=np.float32).reshape(-1, 4)
+        scl = np.ascontiguousarray(scale, dtype=np.float32).reshape(-1)
+        mid = np.ascontiguousarray(mesh_id, dtype=np.uint32).reshape(-1)
+        n = pos.shape[0]
+        if not (rot.shape[0] == n and scl.shape[0] == n and mid.shape[0] == n):
+            raise ValueError("instance columns differ in length")
+        self._check(self._lib.mip_set_instances(self._ctx, pos.ctypes.data, rot.ctypes.data,
+                                                scl.ctypes.data, mid.ctypes.data, n))
+        self.n = n
+
+    def set_instances_device(self, pos_ptr, rot_ptr, scale_ptr, mesh_id_ptr, n):
+        self._check(self._lib.mip_set_instances_device(self._ctx, pos_ptr, rot_ptr, scale_ptr,
+                                                       mesh_id_ptr, int(n)))
+        self.n = int(n)
+
+    # -- per frame --
+    def run_host(self, planes, cam_pos, first_instance_base=0, first_index_base=0,
+                 want=("model", "visible_bitmap", "draw_cmds", "world_aabb")):
+        """Synchronous; results copied back into fresh numpy arrays (PCIe-inclusive)."""
+        n = self.n
+        frame = make_frame(planes, cam_pos, first_instance_base, first_index_base)
+        out = MipOutputs()
+        out.flags = _lib.MIP_OUT_HOST
+        res = {}
+        if "model" in want:
+            res["model"] = np.zeros((n, 16), np.float32)
+            out.model = res["model"].ctypes.data
+        if "visible_bitmap" in want:
+            res["visible_bitmap"] = np.zeros((n + 31) // 32, np.uint32)
+            out.visible_bitmap = res["visible_bitmap"].ctypes.data
+        if "world_aabb" in want:
+            res["world_aabb"] = np.zeros((n, 6), np.float32)
+            out.world_aabb = res["world_aabb"].ctypes.data
+        count = C.c_uint32(0)
+        total = C.c_uint32(0)
+        cmds = None
+        if "draw_cmds" in want:
+            cmds = np.zeros(max(n, 1), DRAW_CMD_DTYPE)
+            out.draw_cmds = cmds.ctypes.data
+            out.draw_count = C.addressof(count)
+            out.draw_index_total = C.addressof(total)
+        self._check(self._lib.mip_run(self._ctx, C.byref(frame), C.byref(out)))
+        if cmds is not None:
+            res["draw_cmds"] = cmds[: count.value].copy()
+            res["draw_count"] = int(count.value)
+            res["draw_index_total"] = int(total.value)
+        return res
+
+    def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0,
+                   draw_index_total=0, world_aabb=0, async_=False):
+        """Device pointers in, nothing copied. `frame` from make_frame()."""
+        out = MipOutputs()
+        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
+        out.model = model or None
+        out.visible_bitmap = visible_bitmap or None
+        out.draw_cmds = draw_cmds or None
+        out.draw_count = draw_count or None
+        out.draw_index_total = draw_index_total or None
+        out.world_aabb = world_aabb or None
+        self._check(self._lib.mip_run(self._ctx, C.byref(frame), C.byref(out)))
+
+    def wait(self):
+        self._check(self._lib.mip_wait(self._ctx))
+
+    def merge_draw_lists(self, chunks_ptr, n_chunks, chunk_stride_bytes, out_cmds_ptr, out_count_ptr,
+                         async_=False):
+        self._check(self._lib.mip_merge_draw_lists(self._ctx, chunks_ptr, int(n_chunks),
+                                                   int(chunk_stride_bytes), out_cmds_ptr,
+                                                   out_count_ptr, 1 if async_ else 0))
+
+    # -- diagnostics --
+    def timings(self):
+        t = MipTimings()
+        self._check(self._lib.mip_get_timings(self._ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in MipTimings._fields_}
+
+    def reset_timings(self):
+        self._check(self._lib.mip_reset_timings(self._ctx))

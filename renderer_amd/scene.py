@@ -1,0 +1,169 @@
+"""Synthetic N-instance scenes: portable splitmix64 PRNG so the same
+instances can be regenerated anywhere, reference-default camera, per-config mesh tables."""
+import numpy as np
+
+from .pipeline import MESH_DTYPE
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+SEED_BASE = 0x5EED0000
+
+# reference defaults: camera at (0,1,2), identity rotation (src/ecs/camera_controller.rs:21),
+# fov 70 deg, near 0.1, far 100 (src/ecs.rs:69-72), window 2000x1000 (src/renderer/instance.rs:45)
+DEFAULT_CAMERA = dict(cam_pos=(0.0, 1.0, 2.0), cam_rot_ijkw=(0.0, 0.0, 0.0, 1.0), aspect=2.0,
+                      fovy_degrees=70.0, near=0.1, far=100.0)
+
+CONFIGS = {
+    1: dict(name="box_1k", n=1024, workload="glTF Box, 1 024 static instances"),
+    2: dict(name="damaged_helmet_100k", n=100_000, workload="DamagedHelmet, 100 k static instances"),
+    3: dict(name="mixed_1m", n=1_000_000, workload="mixed 64-mesh scene, 1 M instances"),
+    4: dict(name="mixed_10m", n=10_000_000, workload="mixed 64-mesh scene, 10 M instances (8 shards)"),
+}
+
+
+def splitmix64(seed, start, count):
+    """Outputs start .. start+count-1 (0-based) of the splitmix64 stream seeded with `seed`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def u01(z):
+    return (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def default_planes():
+    """Frustum planes of the reference's default camera, as float32[24]. Computed in float64
+    from the formulas of src/ecs.rs:66-91 and rounded once (the planes are an input of the
+    path; SURVEY.md §8c KAT 2)."""
+    c = DEFAULT_CAMERA
+    t = np.tan(np.radians(c["fovy_degrees"]) / 2.0)
+    n, f = c["near"], c["far"]
+    proj = np.zeros((4, 4))
+    proj[0, 0] = 1.0 / (c["aspect"] * t)
+    proj[1, 1] = 1.0 / t
+    proj[2, 2] = f / (f - n)
+    proj[2, 3] = -(f * n) / (f - n)
+    proj[3, 2] = 1.0
+    eye = np.array(c["cam_pos"], dtype=np.float64)
+    view = np.eye(4)
+    view[:3, 3] = -eye  # identity rotation: look down +z, up +y (left-handed)
+    m = proj @ view
+    rows = []
+    for k in range(3):
+        rows.append(-(m[3] + m[k]))
+        rows.append(-(m[3] - m[k]))
+    return np.asarray(rows, dtype=np.float64).astype(np.float32).reshape(24)
+
+
+def box_mesh_table():
+    t = np.zeros(1, MESH_DTYPE)
+    t["aabb_min"] = (-0.5, -0.5, -0.5)
+    t["aabb_max"] = (0.5, 0.5, 0.5)
+    t["n_lods"] = 1
+    t["index_len"][0, 0] = 36
+    t["vertex_offset"] = 0
+    return t
+
+
+def _lod_chain(len0):
+    """LOD k targets len0 * 0.5^k indices (scene_loader.rs:741-751), kept only while it shrinks."""
+    lens = [int(len0)]
+    for k in range(1, 6):
+        target = int(np.float32(len0) * np.float32(0.5) ** np.float32(k))
+        target -= target % 3
+        if 0 < target < lens[-1]:
+            lens.append(target)
+    return lens
+
+
+def damaged_helmet_mesh_table():
+    t = np.zeros(1, MESH_DTYPE)
+    t["aabb_min"] = (-0.9475, -1.1872, -0.9010)
+    t["aabb_max"] = (0.9425, 0.8129, 0.9010)
+    lens = _lod_chain(46356)
+    t["n_lods"] = len(lens)
+    off = 0
+    for k, l in enumerate(lens):
+        t["index_len"][0, k] = l
+        t["index_offset"][0, k] = off
+        off += l
+    t["vertex_offset"] = 0
+    return t
+
+
+def mixed_mesh_table(m=64, seed=SEED_BASE + 0x100):
+    z = u01(splitmix64(seed, 0, m * 9)).reshape(m, 9)
+    t = np.zeros(m, MESH_DTYPE)
+    centre = z[:, 0:3] - 0.5
+    half = 0.1 + 1.4 * z[:, 3:6]
+    t["aabb_min"] = (centre - half).astype(np.float32)
+    t["aabb_max"] = (centre + half).astype(np.float32)
+    len0 = np.exp(np.log(36.0) + z[:, 6] * (np.log(70074.0) - np.log(36.0)))
+    len0 = (len0.astype(np.int64) // 3) * 3
+    max_lods = 1 + (z[:, 7] * 6).astype(np.int64).clip(0, 5)
+    index_off = 0
+    vertex_off = 0
+    for k in range(m):
+        lens = _lod_chain(int(len0[k]))[: int(max_lods[k])]
+        t["n_lods"][k] = len(lens)
+        for j, l in enumerate(lens):
+            t["index_len"][k, j] = l
+            t["index_offset"][k, j] = index_off & 0xFFFFFFFF
+            index_off += l
+        t["vertex_offset"][k] = vertex_off
+        vertex_off += max(int(len0[k]) // 3, 3)
+    return t
+
+
+def make_instances(n, n_meshes, seed, box=((-64.0, 64.0), (-32.0, 32.0), (-64.0, 64.0)), first=0):
+    """Instances first .. first+n-1 of the stream: 8 draws per instance
+    (pos x,y,z; quaternion u1,u2,u3; scale; mesh)."""
+    pos = np.empty((n, 3), np.float32)
+    rot = np.empty((n, 4), np.float32)
+    scale = np.empty(n, np.float32)
+    mesh = np.empty(n, np.uint32)
+    step = 1 << 20
+    for b in range(0, n, step):
+        e = min(n, b + step)
+        u = u01(splitmix64(seed, (first + b) * 8, (e - b) * 8)).reshape(e - b, 8)
+        for a in range(3):
+            lo, hi = box[a]
+            pos[b:e, a] = (lo + u[:, a] * (hi - lo)).astype(np.float32)
+        # Shoemake: uniform unit quaternion, stored [i, j, k, w]
+        s1, s2 = np.sqrt(1.0 - u[:, 3]), np.sqrt(u[:, 3])
+        a1, a2 = 2.0 * np.pi * u[:, 4], 2.0 * np.pi * u[:, 5]
+        rot[b:e, 0] = (s1 * np.sin(a1)).astype(np.float32)
+        rot[b:e, 1] = (s1 * np.cos(a1)).astype(np.float32)
+        rot[b:e, 2] = (s2 * np.sin(a2)).astype(np.float32)
+        rot[b:e, 3] = (s2 * np.cos(a2)).astype(np.float32)
+        scale[b:e] = (0.5 + 1.5 * u[:, 6]).astype(np.float32)
+        mesh[b:e] = np.minimum((u[:, 7] * n_meshes).astype(np.uint32), n_meshes - 1)
+    return pos, rot, scale, mesh
+
+
+def make_scene(config, n=None, first=0, all_visible=False):
+    """config 1..4 (BASELINE.json configs[0..3]); `n` overrides the instance count, `first`
+    selects a shard of the stream, all_visible puts every instance inside the frustum cone
+    (worst-case write traffic)."""
+    cfg = CONFIGS[config]
+    n = cfg["n"] if n is None else int(n)
+    if config == 1:
+        meshes = box_mesh_table()
+    elif config == 2:
+        meshes = damaged_helmet_mesh_table()
+    else:
+        meshes = mixed_mesh_table()
+    seed = SEED_BASE + (3 if config == 4 else config)  # config 4 = config 3's generator, larger N
+    box = ((-64.0, 64.0), (-32.0, 32.0), (-64.0, 64.0))
+    if all_visible:
+        box = ((-8.0, 8.0), (-3.0, 5.0), (20.0, 90.0))
+    pos, rot, scale, mesh = make_instances(n, len(meshes), seed, box=box, first=first)
+    return dict(config=config, name=cfg["name"], workload=cfg["workload"], n=n, meshes=meshes,
+                pos=pos, rot=rot, scale=scale, mesh_id=mesh, planes=default_planes(),
+                cam_pos=np.asarray(DEFAULT_CAMERA["cam_pos"], np.float32))

@@ -1,0 +1,46 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+
+def same_floats(a, b):
+    """Element-wise identical as numbers: equal (so +0 == -0), or both NaN."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def float_mismatches(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    return np.argwhere(bad)
+
+
+def assert_parity(got, want, what=""):
+    """Bit-exact for integer outputs (bitmap, count, command bytes, index total); numerically
+    identical floats (stronger than the 1e-5 relative the north star asks) for matrices/AABBs."""
+    assert np.array_equal(got["visible_bitmap"], want["visible_bitmap"]), f"{what}: visibility bitmap"
+    assert got["draw_count"] == want["draw_count"], f"{what}: draw_count {got['draw_count']} vs {want['draw_count']}"
+    assert got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes(), f"{what}: draw command bytes"
+    assert got["draw_index_total"] == want["draw_index_total"], f"{what}: draw_index_total"
+    if "model" in got and "model" in want:
+        mm = float_mismatches(got["model"], want["model"])
+        assert len(mm) == 0, f"{what}: {len(mm)} model matrix entries differ, first {mm[:4].tolist()}"
+    if "world_aabb" in got and "world_aabb" in want:
+        mm = float_mismatches(got["world_aabb"], want["world_aabb"])
+        assert len(mm) == 0, f"{what}: {len(mm)} world AABB entries differ, first {mm[:4].tolist()}"
+
+
+def popcount_bitmap(bitmap):
+    return int(np.unpackbits(np.asarray(bitmap, dtype=np.uint32).view(np.uint8)).sum())
+
+
+def run_oracle(oracle, s, **kw):
+    return oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], **kw)
+
+
+def run_gpu(ra, s, **kw):
+    with ra.InstancePipeline(max_instances=max(s["n"], 1), max_meshes=len(s["meshes"])) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        return p.run_host(s["planes"], s["cam_pos"], **kw)

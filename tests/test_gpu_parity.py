@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on identical inputs.
+Bit-exact visibility bitmap, draw count, command bytes; numerically identical matrices."""
+import numpy as np
+import pytest
+
+from helpers import assert_parity, popcount_bitmap, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import renderer_amd
+
+    renderer_amd.load_library()  # fails loudly if the HIP library is missing
+    return renderer_amd
+
+
+@pytest.mark.parametrize("config,n", [(1, None), (2, None), (3, 200_000)])
+def test_configs_match_oracle(ra, oracle_mod, config, n):
+    s = ra.scene.make_scene(config, n=n)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s, threads=8)
+    assert_parity(got, want, f"config {config}")
+    assert popcount_bitmap(got["visible_bitmap"]) >= got["draw_count"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 513, 1023, 1025, 4097, 65537])
+def test_ragged_sizes(ra, oracle_mod, n):
+    s = ra.scene.make_scene(3, n=n)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, f"n={n}")
+
+
+def test_all_visible_and_none_visible(ra, oracle_mod):
+    s = ra.scene.make_scene(3, n=50_000, all_visible=True)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, "all visible")
+    assert got["draw_count"] == s["n"]
+    s2 = ra.scene.make_scene(3, n=50_000)
+    s2["pos"][:, 2] = -50.0 - np.abs(s2["pos"][:, 2])  # everything behind the camera
+    got = run_gpu(ra, s2)
+    want = run_oracle(oracle_mod, s2)
+    assert_parity(got, want, "none visible")
+    assert got["draw_count"] == 0
+
+
+def _special_values():
+    f = np.float32
+    return np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3.4e38, -3.4e38,
+                     1e19, -1e19, 1e-20, 0.5, 2.0, 10.0, 100.0], dtype=f)
+
+
+def test_non_finite_and_extreme_inputs(ra, oracle_mod):
+    """Every wave gets a few poisoned lanes, so both the general path (taken by the whole
+    wave) and its agreement with the fast path on the finite lanes are exercised."""
+    s = ra.scene.make_scene(3, n=20_000, all_visible=True)
+    rng = np.random.default_rng(7)
+    sv = _special_values()
+    n = s["n"]
+    for col, width in (("pos", 3), ("rot", 4)):
+        rows = rng.choice(n, 600, replace=False)
+        comps = rng.integers(0, width, 600)
+        s[col][rows, comps] = rng.choice(sv, 600)
+    rows = rng.choice(n, 300, replace=False)
+    s["scale"][rows] = rng.choice(sv, 300)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, "special values")
+
+
+def test_denormal_and_huge_scales(ra, oracle_mod):
+    s = ra.scene.make_scene(3, n=8192, all_visible=True)
+    s["scale"][::3] = np.float32(1e-42)
+    s["scale"][1::3] = np.float32(1e30)
+    s["rot"][::5] *= np.float32(1e-20)  # products underflow into denormals
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, "denormal/huge")
+
+
+def test_boxes_tangent_to_planes(ra, oracle_mod):
+    """Instances whose box touches a plane exactly (s - e == 0 => visible) and one ulp either side."""
+    s = ra.scene.make_scene(1, n=4096)
+    n = s["n"]
+    s["rot"][:] = (0, 0, 0, 1)
+    s["scale"][:] = 1.0
+    # far plane: z*0.001001 - 0.1021021 ; near: -2.001 z + 4.102 ; sweep z finely around both
+    z_far = np.float32(102.0) + (np.arange(n // 2, dtype=np.float32) - n // 4) * np.float32(2 ** -17)
+    z_near = np.float32(2.05) + (np.arange(n - n // 2, dtype=np.float32) - n // 4) * np.float32(2 ** -22)
+    s["pos"][:, 0] = 0
+    s["pos"][:, 1] = 1
+    s["pos"][: n // 2, 2] = z_far + np.float32(0.5)
+    s["pos"][n // 2 :, 2] = z_near - np.float32(0.5)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, "tangent")
+    vis = popcount_bitmap(got["visible_bitmap"])
+    assert 0 < vis < n  # the sweep really crosses the planes
+
+
+def test_lod_switch_and_zero_length_meshes(ra, oracle_mod):
+    s = ra.scene.make_scene(3, n=30_000, all_visible=True)
+    m = s["meshes"]
+    m["index_len"][::7, 0] = 0  # LOD0 empty: dropped by compaction when near
+    m["index_len"][3::7, 1] = 0  # LOD1 empty: dropped when far
+    # ring of instances at distance ~10 from the camera (LOD threshold)
+    cam = s["cam_pos"]
+    k = 10_000
+    ang = np.linspace(0, 0.5, k).astype(np.float32)
+    r = np.float32(10.0) + (np.arange(k, dtype=np.float32) - k // 2) * np.float32(2 ** -20)
+    s["pos"][:k, 0] = cam[0] + r * np.sin(ang)
+    s["pos"][:k, 1] = cam[1]
+    s["pos"][:k, 2] = cam[2] + r * np.cos(ang)
+    got = run_gpu(ra, s)
+    want = run_oracle(oracle_mod, s)
+    assert_parity(got, want, "lod")
+    assert got["draw_count"] < popcount_bitmap(got["visible_bitmap"])
+
+
+def test_bases_and_partial_outputs(ra, oracle_mod):
+    s = ra.scene.make_scene(3, n=10_000)
+    with ra.InstancePipeline(max_instances=20_000, max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=123456, first_index_base=0xFFFFFF00)
+        want = run_oracle(oracle_mod, s, first_instance_base=123456, first_index_base=0xFFFFFF00)
+        assert_parity(got, want, "bases")
+        only = p.run_host(s["planes"], s["cam_pos"], want=("visible_bitmap",))
+        assert np.array_equal(only["visible_bitmap"], want0 := run_oracle(oracle_mod, s)["visible_bitmap"])
+        cmds_only = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))
+        assert cmds_only["draw_cmds"].tobytes() == run_oracle(oracle_mod, s)["draw_cmds"].tobytes()
+        # repeated runs (fresh look-back epoch every launch) stay identical
+        for _ in range(20):
+            again = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds", "visible_bitmap"))
+            assert again["draw_cmds"].tobytes() == cmds_only["draw_cmds"].tobytes()
+            assert np.array_equal(again["visible_bitmap"], want0)
+        # shrink the resident set and run again
+        p.set_instances(s["pos"][:777], s["rot"][:777], s["scale"][:777], s["mesh_id"][:777])
+        got = p.run_host(s["planes"], s["cam_pos"])
+        s777 = dict(s, n=777, pos=s["pos"][:777], rot=s["rot"][:777], scale=s["scale"][:777], mesh_id=s["mesh_id"][:777])
+        assert_parity(got, run_oracle(oracle_mod, s777), "shrunk")
+
+
+def test_error_paths(ra):
+    from renderer_amd import MipError
+
+    s = ra.scene.make_scene(1, n=16)
+    with ra.InstancePipeline(max_instances=8, max_meshes=1) as p:
+        with pytest.raises(MipError) as e:
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        assert e.value.code == -6  # mesh table first
+        p.set_mesh_table(s["meshes"])
+        with pytest.raises(MipError) as e:
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        assert e.value.code == -4  # capacity
+        bad = s["mesh_id"][:8].copy()
+        bad[3] = 5
+        with pytest.raises(MipError) as e:
+            p.set_instances(s["pos"][:8], s["rot"][:8], s["scale"][:8], bad)
+        assert e.value.code == -1
+        two = np.concatenate([s["meshes"], s["meshes"]])
+        with pytest.raises(MipError) as e:
+            p.set_mesh_table(two)
+        assert e.value.code == -4
+        nf = s["meshes"].copy()
+        nf["aabb_max"][0, 1] = np.inf
+        with pytest.raises(MipError) as e:
+            p.set_mesh_table(nf)
+        assert e.value.code == -1
+
+
+def test_full_size_properties(ra, oracle_mod):
+    """BASELINE sizes (1 M): size-independent properties plus a full oracle comparison (the
+    threaded oracle finishes 1 M in about a second)."""
+    s = ra.scene.make_scene(3)
+    got = run_gpu(ra, s)
+    cmds = got["draw_cmds"]
+    n = s["n"]
+    # stable order, one command per kept instance, firstIndex is the running sum of indexCount
+    fi = cmds["firstInstance"].astype(np.int64)
+    assert np.all(np.diff(fi) > 0)
+    assert np.all(cmds["instanceCount"] == 1) and np.all(cmds["indexCount"] > 0)
+    run = np.concatenate([[0], np.cumsum(cmds["indexCount"].astype(np.uint64))[:-1]]) & 0xFFFFFFFF
+    vis = np.unpackbits(got["visible_bitmap"].view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert np.all(vis[fi])
+    lens_all_positive = np.all(s["meshes"]["index_len"][:, :2][s["meshes"]["n_lods"] > 1] > 0)
+    if lens_all_positive:
+        assert np.array_equal(cmds["firstIndex"].astype(np.uint64), run)
+        assert len(cmds) == int(vis.sum())
+    assert got["draw_index_total"] == int(cmds["indexCount"].astype(np.uint64).sum() & 0xFFFFFFFF)
+    # matrices: bottom row is (0,0,0,1), translation column is the position
+    m = got["model"].reshape(n, 4, 4)  # [col][row]
+    assert np.all(m[:, :3, 3] == 0) and np.all(m[:, 3, 3] == 1)
+    assert np.array_equal(m[:, 3, :3], s["pos"])
+    want = run_oracle(oracle_mod, s, threads=8)
+    assert_parity(got, want, "1M")
