@@ -98,12 +98,25 @@ def kernel_event_time(torch, step, steps, warmup):
     return float(ms.mean()), float(np.median(ms)), float(ms.min())
 
 
+def host_cores():
+    """Threads for the CPU leg: the affinity mask, capped by the cgroup CPU quota if there is one
+    and by 16 (a 1-GPU box's CPU share on the pool this runs on)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, int(os.environ.get("MIP_BENCH_MAX_THREADS", "16"))))
+
+
 def cpu_baseline(scene_dict, seconds):
     """The oracle (a CPU port of the reference path) on this box's host cores, bounded sample."""
     import oracle
 
     oracle.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     s = scene_dict
     n = s["n"]
     sample_n = min(n, 1_000_000)
@@ -155,7 +168,11 @@ def main():
     n_global = n_local * world
     s = scene.make_scene(args.config, n=n_local, first=rank * n_local, all_visible=args.all_visible)
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # The context enqueues on a real (non-null) torch stream made current here, so that
+    # torch.cuda.Event and the NCCL ops are ordered with the kernels.
+    torch_stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
     pipe = renderer_amd.InstancePipeline(max_instances=n_local, max_meshes=len(s["meshes"]),
                                          device=local_rank, stream=stream)
     pipe.set_mesh_table(s["meshes"])

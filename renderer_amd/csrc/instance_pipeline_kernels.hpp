@@ -55,7 +55,10 @@ struct KernelArgs {
   uint32_t* draw_count;         // with cmds
   uint32_t* index_total;        // optional
   float* world_aabb;            // n*6 or null
-  unsigned long long* status;   // 2 granules per tile
+  unsigned long long* status0;  // level 0: 2 tagged granules per tile
+  unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
+  uint32_t groups_cap;
+  uint32_t group_shift;         // log2(tiles per group), <= 6
   uint32_t* error_flag;         // host-mapped
   uint32_t n;
   uint32_t n_tiles;
@@ -65,7 +68,19 @@ struct KernelArgs {
   uint32_t first_index_base;
   float planes[24];
   float cam[3];
+#ifdef MIP_DEBUG_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
+#endif
 };
+
+#ifdef MIP_DEBUG_STAMPS
+#define MIP_STAMP(k)                                                                       \
+  do {                                                                                     \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define MIP_STAMP(k) do { } while (0)
+#endif
 
 // Largest q with sqrt_rn(q) <= 10: pick_lod tests `magnitude() > 10.0`
 // (helpers.rs:4-6) and magnitude = sqrt(norm_squared) correctly rounded, so
@@ -246,15 +261,36 @@ __device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&p
 }
 
 // ---------------------------------------------------------------------------------------
-// tile status granules (decoupled look-back)
+// cross-tile prefix: one hop, no chains
 // ---------------------------------------------------------------------------------------
-// Two 8-byte granules per tile, each written by ONE relaxed agent-scope atomic store
-// (global_store_dwordx2 sc1) and read by relaxed agent-scope atomic loads:
-//   granule 0 = { tag, count }   granule 1 = { tag, Σ index_len }
-//   tag = epoch << 1 | is_inclusive_prefix
-// The epoch changes every launch, so the array is never cleared; a reader accepts a
-// tile only when both granules carry the same tag of the current epoch. No payload is
-// handed off behind these words, so no release/acquire fence is involved.
+// A tile's exclusive prefix (count, Σ index_len) over all earlier tiles is assembled from
+// words that every tile publishes as soon as it knows its own aggregate — it never depends
+// on another tile having finished its own look-up, so the wait is one memory round trip
+// after the slowest predecessor has published (measured: a hop costs ~1 µs on an idle
+// chip and ~3 µs behind streaming traffic, so chains of hops are what must be avoided).
+//
+//   level 0  status0[tile]   two 8-byte granules {tag, count} {tag, Σ index_len}, each ONE
+//                            relaxed agent-scope atomic store (global_store_dwordx2 sc1);
+//                            tag = launch epoch, so the array is never cleared.
+//   level 1  acc1[parity][g] one 64-bit accumulator per group of 2^group_shift consecutive
+//                            tiles; every tile of the group adds
+//                            {Σ index_len : 32 | arrivals : 12 | count : 20} with one
+//                            no-return agent-scope atomic add (executes at the memory side).
+//                            A group is complete when arrivals == tiles per group. The
+//                            buffer of the other parity is zeroed for the next launch by
+//                            the first tile of each group; the host clears both whenever
+//                            the instance count changes.
+//
+//   prefix(tile) = Σ acc1[g' < g]  +  Σ status0[first tile of g .. tile-1]
+//
+// No payload is handed off behind these words (every tile writes its own commands), so no
+// release/acquire fence is involved; readers use relaxed agent-scope atomic loads (sc1).
+
+constexpr uint32_t kAccCountBits = 20, kAccArrivalBits = 12;
+// Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
+// words would put all of that traffic (and the atomics) on one or two memory channels.
+constexpr uint32_t kAccStrideWords = 32;
+constexpr uint32_t kLevel1Unroll = 4;  // level-1 words each lane keeps in flight per round
 
 __device__ __forceinline__ void status_store(unsigned long long* p, uint32_t tag, uint32_t value) {
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -264,51 +300,98 @@ __device__ __forceinline__ unsigned long long status_load(const unsigned long lo
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Called by ONE lane of the tile once its aggregate is known.
+__device__ __forceinline__ void publish_aggregate(const KernelArgs& a, uint32_t tile, uint32_t count, uint32_t sum) {
+  unsigned long long* e = &a.status0[2 * (size_t)tile];
+  status_store(e, a.epoch, count);
+  status_store(e + 1, a.epoch, sum);
+  const uint32_t group = tile >> a.group_shift;
+  const uint32_t parity = a.epoch & 1u;
+  const unsigned long long add = ((unsigned long long)sum << 32) | (1ull << kAccCountBits) | count;
+  (void)__hip_atomic_fetch_add(&a.acc1[((size_t)parity * a.groups_cap + group) * kAccStrideWords], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((tile & ((1u << a.group_shift) - 1u)) == 0u)  // first tile of the group: reset the next launch's word
+    __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz realtime counter
 
-// Run by wave 0 of the workgroup. Returns the exclusive prefix (count, Σ index_len) of `tile`.
-__device__ __forceinline__ void look_back(const KernelArgs& a, uint32_t tile, uint32_t lane,
-                                          uint32_t& base_count, uint32_t& base_sum) {
-  uint32_t excl_c = 0, excl_s = 0;
-  int32_t base = (int32_t)tile - 1;
+// Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`.
+__device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t tile, uint32_t lane,
+                                               uint32_t& base_count, uint32_t& base_sum) {
+  const uint32_t group = tile >> a.group_shift;
+  const uint32_t group_first = group << a.group_shift;
+  const uint32_t r = tile - group_first;  // earlier tiles of the own group (< 64)
+  const uint32_t per_group = 1u << a.group_shift;
+  const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  bool give_up = false;
-  while (base >= 0 && !give_up) {
-    const int32_t idx = base - (int32_t)lane;  // lane 0 looks at the nearest predecessor
-    const bool valid = idx >= 0;
-    bool ready = !valid, is_prefix = false;
-    uint32_t c = 0, s = 0;
+  uint32_t c_total = 0, s_total = 0;
+  bool ok = true;
+
+  // level 0: lane l < r reads the aggregate of tile group_first + l
+  const bool v0 = lane < r;
+  const unsigned long long* e0 = &a.status0[2 * (size_t)(group_first + (v0 ? lane : 0u))];
+  bool ready0 = !v0;
+  uint32_t c0 = 0, s0 = 0;
+
+  for (uint32_t g0 = 0; ok && (g0 < group || g0 == 0u); g0 += 64u * kLevel1Unroll) {
+    bool ready1[kLevel1Unroll];
+    uint32_t c1[kLevel1Unroll], s1[kLevel1Unroll];
+#pragma unroll
+    for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
+      ready1[k] = !(g0 + 64u * k + lane < group);
+      c1[k] = 0;
+      s1[k] = 0;
+    }
     for (;;) {
-      if (!ready) {
-        const unsigned long long g0 = status_load(&a.status[2 * (size_t)idx]);
-        const unsigned long long g1 = status_load(&a.status[2 * (size_t)idx + 1]);
-        const uint32_t t0 = (uint32_t)(g0 >> 32), t1 = (uint32_t)(g1 >> 32);
-        if ((t0 >> 1) == a.epoch && t0 == t1) {
-          ready = true;
-          is_prefix = (t0 & 1u) != 0;
-          c = (uint32_t)g0;
-          s = (uint32_t)g1;
+      bool all = ready0;
+      if (!ready0) {
+        const unsigned long long g_c = status_load(e0), g_s = status_load(e0 + 1);
+        if ((uint32_t)(g_c >> 32) == a.epoch && (uint32_t)(g_s >> 32) == a.epoch) {
+          ready0 = true;
+          c0 = (uint32_t)g_c;
+          s0 = (uint32_t)g_s;
         }
+        all = ready0;
       }
-      if (__all(ready)) break;
-      if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {
-        give_up = true;  // wave-uniform: s_memrealtime is scalar
+#pragma unroll
+      for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
+        if (!ready1[k]) {
+          const unsigned long long w = status_load(&acc[(size_t)(g0 + 64u * k + lane) * kAccStrideWords]);
+          if (((uint32_t)w >> kAccCountBits) == per_group) {  // every tile of that group has added
+            ready1[k] = true;
+            c1[k] = (uint32_t)w & ((1u << kAccCountBits) - 1u);
+            s1[k] = (uint32_t)(w >> 32);
+          }
+        }
+        all = all && ready1[k];
+      }
+#ifdef MIP_DEBUG_STAMPS
+      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
+      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
+#endif
+      if (__all(all)) break;
+      if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
+        ok = false;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
-    if (give_up) break;
-    const unsigned long long pmask = __ballot(valid && is_prefix);
-    const uint32_t last = pmask ? (uint32_t)__builtin_ctzll(pmask) : 63u;  // nearest tile holding a prefix
-    const bool take = valid && lane <= last;
-    excl_c += wave_sum(take ? c : 0u);
-    excl_s += wave_sum(take ? s : 0u);
-    if (pmask) break;
-    base -= 64;
+#pragma unroll
+    for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
+      c_total += c1[k];
+      s_total += s1[k];
+    }
   }
-  if (give_up && lane == 0) atomicOr(a.error_flag, kErrTimeout);
-  base_count = excl_c;
-  base_sum = excl_s;
+  c_total += c0;
+  s_total += s0;
+  if (ok) {
+    base_count = wave_sum(c_total);
+    base_sum = wave_sum(s_total);
+  } else {
+    if (lane == 0) __hip_atomic_store(a.error_flag, kErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    base_count = 0;
+    base_sum = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -328,6 +411,7 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
   const uint32_t i = tile_first + tid;
   const bool active = i < a.n;
   const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
+  MIP_STAMP(0);
 
   // ---- loads: 36 B per instance ----
   const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
@@ -358,6 +442,7 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     instance_fast(r, px, py, pz, sc, mb, inst);
   }
 
+  MIP_STAMP(1);
   // ---- frustum test, LOD, command length ----
   const bool culled = coarse_culled(inst, a.planes);
   const bool visible = active && !culled;
@@ -397,47 +482,52 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
   }
 
   const bool want_cmds = a.cmds != nullptr;
-  const uint32_t tag_aggregate = a.epoch << 1, tag_prefix = tag_aggregate | 1u;
-  if (want_cmds && tid == 0) {
-    // tile 0 has no predecessor: its aggregate is already its inclusive prefix
-    const uint32_t tag = tile == 0 ? tag_prefix : tag_aggregate;
-    status_store(&a.status[2 * (size_t)tile], tag, tile_count);
-    status_store(&a.status[2 * (size_t)tile + 1], tag, tile_sum);
-  }
+  if (want_cmds && tid == 0) publish_aggregate(a, tile, tile_count, tile_sum);
+  MIP_STAMP(2);
 
-  // ---- model matrices: 4 store instructions per wave, each 1 KiB contiguous ----
-  if (a.model) {
-    const uint32_t wave_first = wave * 64u;
-    const float* src = &s_mat[wave_first * 12];
-    float4* out = a.model + ((size_t)tile_first + wave_first) * 4;
-    const uint32_t col = lane & 3u;
-#pragma unroll
-    for (uint32_t s4 = 0; s4 < 4; ++s4) {
-      const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
-      const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
-      const uint32_t bits = s_row3[wave_first + local];
-      float w = (col == 3u) ? 1.0f : 0.0f;
-      if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
-      if (tile_first + wave_first + local < a.n)
-        out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
+  // Bulk stores of this wave: matrices, visibility words, optional AABBs. Wave 0 issues
+  // them only AFTER it has resolved the tile prefix: loads return in order with stores
+  // (vmcnt counts both), so a poll behind 4 KiB of stores would wait for their acks.
+  auto bulk_stores = [&]() {
+    // ---- model matrices: 4 store instructions per wave, each 1 KiB contiguous ----
+    if (a.model) {
+      const uint32_t wave_first = wave * 64u;
+      const float* src = &s_mat[wave_first * 12];
+      float4* out = a.model + ((size_t)tile_first + wave_first) * 4;
+      const uint32_t col = lane & 3u;
+  #pragma unroll
+      for (uint32_t s4 = 0; s4 < 4; ++s4) {
+        const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
+        const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
+        const uint32_t bits = s_row3[wave_first + local];
+        float w = (col == 3u) ? 1.0f : 0.0f;
+        if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
+        if (tile_first + wave_first + local < a.n)
+          out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
+      }
     }
-  }
 
-  // ---- visibility bitmap: one 64-bit ballot per wave, written as two words ----
-  if (a.bitmap && lane < 2u) {
-    const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
-    if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
-  }
+    // ---- visibility bitmap: one 64-bit ballot per wave, written as two words ----
+    if (a.bitmap && lane < 2u) {
+      const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
+      if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
+    }
 
-  // ---- optional world AABB (mins, maxs) as the ECS component holds it ----
-  if (a.world_aabb && active) {
-    float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
-    o2[0] = make_float2(inst.mins[0], inst.mins[1]);
-    o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
-    o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
-  }
+    // ---- optional world AABB (mins, maxs) as the ECS component holds it ----
+    if (a.world_aabb && active) {
+      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
+      o2[0] = make_float2(inst.mins[0], inst.mins[1]);
+      o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
+      o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
+    }
 
-  if (!want_cmds) return;
+  };
+
+  if (!want_cmds) {
+    bulk_stores();
+    return;
+  }
+  if (wave != 0) bulk_stores();
 
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
@@ -449,16 +539,11 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
   }
 
-  // ---- decoupled look-back (wave 0), then publish the inclusive prefix ----
+  MIP_STAMP(3);
+  // ---- exclusive prefix over the earlier tiles (wave 0) ----
   if (wave == 0) {
     uint32_t base_count = 0, base_sum = 0;
-    if (tile > 0) {
-      look_back(a, tile, lane, base_count, base_sum);
-      if (lane == 0) {
-        status_store(&a.status[2 * (size_t)tile], tag_prefix, base_count + tile_count);
-        status_store(&a.status[2 * (size_t)tile + 1], tag_prefix, base_sum + tile_sum);
-      }
-    }
+    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
     if (lane == 0) {
       s_base[0] = base_count;
       s_base[1] = base_sum;
@@ -469,6 +554,7 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     }
   }
   __syncthreads();
+  MIP_STAMP(4);
 
   // ---- coalesced copy-out of the tile's commands ----
   const uint32_t base_count = s_base[0];
@@ -480,6 +566,8 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     if (j % kCmdWords == 2u) v += first_index_add;
     out[j] = v;
   }
+  if (wave == 0) bulk_stores();
+  MIP_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------

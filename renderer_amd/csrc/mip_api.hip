@@ -35,8 +35,11 @@ struct MipContext {
   mip::MeshEntry* d_meshes = nullptr;
   int32_t* d_vertex_offset = nullptr;
   // look-back state
-  unsigned long long* d_status = nullptr;
+  unsigned long long* d_status = nullptr;  // level-0 entries, then 2 x groups_cap accumulators
+  size_t status_bytes = 0;
+  uint32_t acc1_offset_words = 0, groups_cap = 0;
   uint32_t epoch = 0;
+  bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   uint32_t* d_scalars = nullptr;  // [0] draw_count, [1] index_total, [2..3] merge out
@@ -50,6 +53,9 @@ struct MipContext {
   MipTimings timings{};
   bool pending_async = false;
   char err[512] = {0};
+#ifdef MIP_DEBUG_STAMPS
+  unsigned long long* d_stamps = nullptr;
+#endif
 };
 
 namespace {
@@ -163,14 +169,22 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_id, cap * 4));
     MIP_HIP(ctx, hipMalloc(&ctx->d_meshes, mcap * sizeof(mip::MeshEntry)));
     MIP_HIP(ctx, hipMalloc(&ctx->d_vertex_offset, mcap * 4));
-    const size_t status_bytes = (size_t)tiles_for((uint32_t)cap) * 16;
-    MIP_HIP(ctx, hipMalloc(&ctx->d_status, status_bytes));
-    MIP_HIP(ctx, hipMemset(ctx->d_status, 0, status_bytes));  // epoch 0 is never used
+    const size_t tiles_cap = tiles_for((uint32_t)cap);
+    // smallest group the kernel may pick is 16 tiles (group_shift 4)
+    ctx->groups_cap = (uint32_t)((tiles_cap + 15) / 16);
+    ctx->acc1_offset_words = (uint32_t)(tiles_cap * 2);
+    ctx->status_bytes = tiles_cap * 16 + (size_t)ctx->groups_cap * 2 * 8 * mip::kAccStrideWords;
+    MIP_HIP(ctx, hipMalloc(&ctx->d_status, ctx->status_bytes));
+    MIP_HIP(ctx, hipMemset(ctx->d_status, 0, ctx->status_bytes));  // epoch 0 is never used
     MIP_HIP(ctx, hipMalloc(&ctx->d_scalars, 64));
     MIP_HIP(ctx, hipMemset(ctx->d_scalars, 0, 64));
     MIP_HIP(ctx, hipHostMalloc(&ctx->h_error, 64, hipHostMallocMapped));
     std::memset(ctx->h_error, 0, 64);
     MIP_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_error, ctx->h_error, 0));
+#ifdef MIP_DEBUG_STAMPS
+    MIP_HIP(ctx, hipMalloc(&ctx->d_stamps, tiles_cap * 64));
+    MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
+#endif
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
     MIP_HIP(ctx, hipEventCreate(&ctx->ev1));
     return MIP_OK;
@@ -229,6 +243,7 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
     MIP_HIP(ctx, hipMemcpy(ctx->d_scale, scale, (size_t)n * 4, kind));
     MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind));
   }
+  if (n != ctx->n) ctx->status_dirty = true;  // tile/group geometry changes with n
   ctx->n = n;
   ctx->have_instances = true;
   return MIP_OK;
@@ -280,23 +295,33 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : ctx->d_scalars + 0) : nullptr;
   a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : ctx->d_scalars + 1) : nullptr;
   a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
-  a.status = ctx->d_status;
+  a.status0 = ctx->d_status;
+  a.acc1 = ctx->d_status + ctx->acc1_offset_words;
+  a.groups_cap = ctx->groups_cap;
   a.error_flag = ctx->d_error;
   a.n = n;
-  a.n_tiles = tiles_for(n);
   a.bitmap_words = words;
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
   std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
+#ifdef MIP_DEBUG_STAMPS
+  a.stamps = ctx->d_stamps;
+#endif
 
-  // A fresh epoch per launch stands in for clearing the tile-status array. On wrap
-  // (every 2^31-2 launches) clear it once and start over.
-  if (ctx->epoch >= 0x7ffffffeu) {
-    MIP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, (size_t)tiles_for(ctx->max_instances ? ctx->max_instances : 1) * 16, ctx->stream));
-    ctx->epoch = 0;
+  // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh epoch per launch
+  // tags the level-0 words; the level-1 accumulators alternate between two buffers, the
+  // kernel zeroing the other one. Launches without draw commands do not touch the state.
+  a.n_tiles = tiles_for(n);
+  a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
+  if (a.cmds && n) {
+    if (ctx->status_dirty || ctx->epoch >= 0xfffffffeu) {
+      MIP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, ctx->status_bytes, ctx->stream));
+      ctx->status_dirty = false;
+      ctx->epoch = 0;
+    }
+    a.epoch = ++ctx->epoch;
   }
-  a.epoch = ++ctx->epoch;
 
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0;
   if (n == 0) {
@@ -407,5 +432,23 @@ int32_t mip_reset_timings(MipContext* ctx) {
 }
 
 uint32_t mip_instance_count(const MipContext* ctx) { return ctx ? ctx->n : 0; }
+
+#ifdef MIP_DEBUG_STAMPS
+// Diagnostic build only (libmi_instance_pipeline_dbg.so): copy out the per-tile stamps.
+int32_t mip_debug_read_stamps(MipContext* ctx, unsigned long long* out, uint32_t n_tiles) {
+  if (!ctx || !out) return MIP_ERR_INVALID_ARGUMENT;
+  MIP_HIP(ctx, hipSetDevice(ctx->device));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MIP_HIP(ctx, hipMemcpy(out, ctx->d_stamps, (size_t)n_tiles * 64, hipMemcpyDeviceToHost));
+  return MIP_OK;
+}
+int32_t mip_debug_write_stamps(MipContext* ctx, const unsigned long long* in, uint32_t n_tiles) {
+  if (!ctx || !in) return MIP_ERR_INVALID_ARGUMENT;
+  MIP_HIP(ctx, hipSetDevice(ctx->device));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MIP_HIP(ctx, hipMemcpy(ctx->d_stamps, in, (size_t)n_tiles * 64, hipMemcpyHostToDevice));
+  return MIP_OK;
+}
+#endif
 
 }  // extern "C"

@@ -183,14 +183,15 @@ def test_full_size_properties(ra, oracle_mod):
     fi = cmds["firstInstance"].astype(np.int64)
     assert np.all(np.diff(fi) > 0)
     assert np.all(cmds["instanceCount"] == 1) and np.all(cmds["indexCount"] > 0)
-    run = np.concatenate([[0], np.cumsum(cmds["indexCount"].astype(np.uint64))[:-1]]) & 0xFFFFFFFF
+    csum = np.cumsum(cmds["indexCount"].astype(np.uint64))
+    run = np.concatenate([np.zeros(1, np.uint64), csum[:-1]]) & np.uint64(0xFFFFFFFF)
     vis = np.unpackbits(got["visible_bitmap"].view(np.uint8), bitorder="little")[:n].astype(bool)
     assert np.all(vis[fi])
     lens_all_positive = np.all(s["meshes"]["index_len"][:, :2][s["meshes"]["n_lods"] > 1] > 0)
     if lens_all_positive:
         assert np.array_equal(cmds["firstIndex"].astype(np.uint64), run)
         assert len(cmds) == int(vis.sum())
-    assert got["draw_index_total"] == int(cmds["indexCount"].astype(np.uint64).sum() & 0xFFFFFFFF)
+    assert got["draw_index_total"] == int(csum[-1]) & 0xFFFFFFFF
     # matrices: bottom row is (0,0,0,1), translation column is the position
     m = got["model"].reshape(n, 4, 4)  # [col][row]
     assert np.all(m[:, :3, 3] == 0) and np.all(m[:, 3, 3] == 1)
