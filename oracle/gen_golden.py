@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the C oracle (TEST INFRASTRUCTURE).
+
+The reference has no tests, fixtures or golden vectors for this path and cannot be built
+or run here (nightly Rust, un-vendored crates), so these vectors are produced by the
+oracle itself: they pin the oracle against regressions / toolchain differences and give the
+GPU tests committed expected outputs, but they are NOT outputs of the reference (parity
+unpinned — see oracle/mip_oracle.h).
+
+    python oracle/gen_golden.py          # rewrites tests/golden/
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from renderer_amd import scene  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def special_scene(n=513):
+    """Hand-built edge cases followed by random filler."""
+    s = scene.make_scene(3, n=n, all_visible=True)
+    pos, rot, scl, mid = s["pos"], s["rot"], s["scale"], s["mesh_id"]
+    m = s["meshes"]
+    m["index_len"][5, 0] = 0  # a mesh whose LOD0 is empty: dropped by compaction when near
+    r = np.float32(np.sqrt(0.5))
+    cases = [
+        # pos, rot[i,j,k,w], scale, mesh
+        ((1, 2, 30), (0, 0, 0, 1), 1.0, 0),                 # identity: M = T
+        ((0, 1, 40), (0, r, 0, r), 2.0, 1),                 # 90 degrees about +Y, scale 2
+        ((30, 20, -40.1), (0, 0, 0, 1), 1.0, 2),            # a reference light position (main.rs:369)
+        ((0.1, 17, 0.1), (0, 0, 0, 1), 1.0, 3),             # the other one (main.rs:378)
+        ((0, 1, 50), (0, 0, 0, 1), 0.0, 4),                 # zero scale
+        ((0, 1, 50), (0, 0, 0, 2), 1.0, 4),                 # non-unit quaternion (not renormalised)
+        ((np.nan, 1, 50), (0, 0, 0, 1), 1.0, 4),            # NaN position => visible
+        ((0, 1, 50), (np.inf, 0, 0, 1), 1.0, 4),            # inf in the quaternion
+        ((0, 1, 50), (0, 0, 0, 1), np.inf, 4),              # inf scale
+        ((0, 1, 50), (0, 0, 0, 1), np.nan, 4),              # NaN scale
+        ((np.inf, 1, 50), (0, 0, 0, 1), 1.0, 4),            # inf position
+        ((0, 1, 5), (0, 0, 0, 1), 1.0, 5),                  # near (LOD 0) with an empty LOD 0 => no command
+        ((0, 1, 12), (0, 0, 0, 1), 1.0, 0),                 # distance exactly 10 from the camera => LOD 0
+        ((0, 1, np.nextafter(np.float32(12), np.float32(13))), (0, 0, 0, 1), 1.0, 0),  # just beyond => LOD 1
+        ((0, 1, -50), (0, 0, 0, 1), 1.0, 0),                # behind the camera: culled
+        ((0, 1, 1e-42), (1e-20, 1e-20, 0, 1), 1e-38, 0),    # denormals
+    ]
+    for k, (p, q, sc, me) in enumerate(cases):
+        pos[k] = p
+        rot[k] = q
+        scl[k] = sc
+        mid[k] = me
+    return s
+
+
+def dump(name, s, **extra):
+    r = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], **extra)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        pos=s["pos"], rot=s["rot"], scale=s["scale"], mesh_id=s["mesh_id"], meshes=s["meshes"],
+        planes=s["planes"], cam_pos=s["cam_pos"],
+        first_instance_base=np.uint32(extra.get("first_instance_base", 0)),
+        first_index_base=np.uint32(extra.get("first_index_base", 0)),
+        model=r["model"], world_aabb=r["world_aabb"], visible_bitmap=r["visible_bitmap"],
+        coarse_culled=r["coarse_culled"], draw_cmds=r["draw_cmds"],
+        draw_count=np.uint32(r["draw_count"]), draw_index_total=np.uint32(r["draw_index_total"]),
+    )
+    print(f"{name}: n={s['n']} visible={int((1 - r['coarse_culled']).sum())} cmds={r['draw_count']}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    oracle.build()
+    dump("box_1024", scene.make_scene(1))  # BASELINE config 1, full outputs
+    for n in (1, 63, 64, 65, 257):
+        dump(f"mixed_{n}", scene.make_scene(3, n=n, all_visible=(n < 100)))
+    dump("mixed_4097_bases", scene.make_scene(3, n=4097), first_instance_base=1000, first_index_base=0xFFFFF000)
+    dump("helmet_2000", scene.make_scene(2, n=2000))
+    dump("special_513", special_scene())
+    np.save(os.path.join(OUT, "default_planes.npy"), scene.default_planes())
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib", "libmi_instance_pipeline.so")
+if os.environ.get("MIP_LIBRARY"):  # tuning/diagnostic builds only (tools/); never set by the product path
+    _SO = os.path.abspath(os.environ["MIP_LIBRARY"])
 
 MIP_OK = 0
 ERR_NAMES = {

@@ -28,6 +28,12 @@
 
 namespace mip {
 
+// Register budget: minimum waves per SIMD the kernel is compiled for (k workgroups of 256
+// threads per CU <=> k waves per SIMD). Overridable to build tuning variants.
+#ifndef MIP_MIN_WAVES_PER_SIMD
+#define MIP_MIN_WAVES_PER_SIMD 6
+#endif
+
 constexpr uint32_t kTile = 256;           // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
@@ -55,7 +61,7 @@ struct KernelArgs {
   uint32_t* draw_count;         // with cmds
   uint32_t* index_total;        // optional
   float* world_aabb;            // n*6 or null
-  unsigned long long* status0;  // level 0: 2 tagged granules per tile
+  unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   uint32_t groups_cap;
   uint32_t group_shift;         // log2(tiles per group), <= 6
@@ -269,17 +275,20 @@ __device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&p
 // after the slowest predecessor has published (measured: a hop costs ~1 µs on an idle
 // chip and ~3 µs behind streaming traffic, so chains of hops are what must be avoided).
 //
-//   level 0  status0[tile]   two 8-byte granules {tag, count} {tag, Σ index_len}, each ONE
-//                            relaxed agent-scope atomic store (global_store_dwordx2 sc1);
-//                            tag = launch epoch, so the array is never cleared.
+//   level 0  status0[tile]   ONE 8-byte granule {Σ index_len : 32 | tag : 23 | count : 9},
+//                            written by one relaxed agent-scope atomic store
+//                            (global_store_dwordx2 sc1); tag = launch epoch (never 0), so
+//                            the array is never cleared between launches.
 //   level 1  acc1[parity][g] one 64-bit accumulator per group of 2^group_shift consecutive
-//                            tiles; every tile of the group adds
+//                            tiles, 256 B apart (packed words put every tile's reads and
+//                            the atomics on one or two memory channels: measured 5x
+//                            slower); every tile of the group adds
 //                            {Σ index_len : 32 | arrivals : 12 | count : 20} with one
 //                            no-return agent-scope atomic add (executes at the memory side).
 //                            A group is complete when arrivals == tiles per group. The
 //                            buffer of the other parity is zeroed for the next launch by
-//                            the first tile of each group; the host clears both whenever
-//                            the instance count changes.
+//                            the first tile of each group; the host clears everything
+//                            whenever the instance count changes or the tag wraps.
 //
 //   prefix(tile) = Σ acc1[g' < g]  +  Σ status0[first tile of g .. tile-1]
 //
@@ -290,11 +299,10 @@ constexpr uint32_t kAccCountBits = 20, kAccArrivalBits = 12;
 // Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
 // words would put all of that traffic (and the atomics) on one or two memory channels.
 constexpr uint32_t kAccStrideWords = 32;
-constexpr uint32_t kLevel1Unroll = 4;  // level-1 words each lane keeps in flight per round
-
-__device__ __forceinline__ void status_store(unsigned long long* p, uint32_t tag, uint32_t value) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+constexpr uint32_t kLevel1Unroll = 2;  // level-1 words each lane keeps in flight per round
+constexpr uint32_t kTagBits = 23, kTileCountBits = 9;
+constexpr uint32_t kMaxEpoch = (1u << kTagBits) - 1u;
+static_assert(kTile < (1u << kTileCountBits), "tile count must fit its field");
 
 __device__ __forceinline__ unsigned long long status_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -302,9 +310,8 @@ __device__ __forceinline__ unsigned long long status_load(const unsigned long lo
 
 // Called by ONE lane of the tile once its aggregate is known.
 __device__ __forceinline__ void publish_aggregate(const KernelArgs& a, uint32_t tile, uint32_t count, uint32_t sum) {
-  unsigned long long* e = &a.status0[2 * (size_t)tile];
-  status_store(e, a.epoch, count);
-  status_store(e + 1, a.epoch, sum);
+  const unsigned long long granule = ((unsigned long long)sum << 32) | ((unsigned long long)a.epoch << kTileCountBits) | count;
+  __hip_atomic_store(&a.status0[tile], granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t group = tile >> a.group_shift;
   const uint32_t parity = a.epoch & 1u;
   const unsigned long long add = ((unsigned long long)sum << 32) | (1ull << kAccCountBits) | count;
@@ -329,7 +336,7 @@ __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t til
 
   // level 0: lane l < r reads the aggregate of tile group_first + l
   const bool v0 = lane < r;
-  const unsigned long long* e0 = &a.status0[2 * (size_t)(group_first + (v0 ? lane : 0u))];
+  const unsigned long long* e0 = &a.status0[group_first + (v0 ? lane : 0u)];
   bool ready0 = !v0;
   uint32_t c0 = 0, s0 = 0;
 
@@ -345,11 +352,11 @@ __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t til
     for (;;) {
       bool all = ready0;
       if (!ready0) {
-        const unsigned long long g_c = status_load(e0), g_s = status_load(e0 + 1);
-        if ((uint32_t)(g_c >> 32) == a.epoch && (uint32_t)(g_s >> 32) == a.epoch) {
+        const unsigned long long g = status_load(e0);
+        if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
           ready0 = true;
-          c0 = (uint32_t)g_c;
-          s0 = (uint32_t)g_s;
+          c0 = (uint32_t)g & ((1u << kTileCountBits) - 1u);
+          s0 = (uint32_t)(g >> 32);
         }
         all = ready0;
       }
@@ -398,12 +405,11 @@ __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t til
 // the kernel
 // ---------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pipeline_kernel(const KernelArgs a) {
   __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
   __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
   __shared__ __attribute__((aligned(16))) uint32_t s_cmd[kTile * kCmdWords];
   __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
-  __shared__ uint32_t s_base[2];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t tile = blockIdx.x;
@@ -527,7 +533,6 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     bulk_stores();
     return;
   }
-  if (wave != 0) bulk_stores();
 
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
@@ -538,35 +543,36 @@ __global__ __launch_bounds__(kTile, 6) void mip_instance_pipeline_kernel(const K
     c[3] = (uint32_t)a.vertex_offset[mesh];                   // vertexOffset, :66
     c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
   }
-
+  __syncthreads();  // s_cmd complete
   MIP_STAMP(3);
-  // ---- exclusive prefix over the earlier tiles (wave 0) ----
-  if (wave == 0) {
-    uint32_t base_count = 0, base_sum = 0;
-    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
-    if (lane == 0) {
-      s_base[0] = base_count;
-      s_base[1] = base_sum;
-      if (tile == a.n_tiles - 1u) {
-        *a.draw_count = base_count + tile_count;
-        if (a.index_total) *a.index_total = base_sum + tile_sum;
-      }
-    }
+
+  // Waves 1-3 are finished once their stores are issued: they exit and free their
+  // registers and wave slots for the next workgroup while wave 0 alone waits for the
+  // tile's prefix and copies the commands out.
+  if (wave != 0) {
+    bulk_stores();
+    return;
   }
-  __syncthreads();
+
+  // ---- exclusive prefix over the earlier tiles, before any bulk store of this wave ----
+  uint32_t base_count = 0, base_sum = 0;
+  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+  if (lane == 0 && tile == a.n_tiles - 1u) {
+    *a.draw_count = base_count + tile_count;
+    if (a.index_total) *a.index_total = base_sum + tile_sum;
+  }
   MIP_STAMP(4);
 
   // ---- coalesced copy-out of the tile's commands ----
-  const uint32_t base_count = s_base[0];
-  const uint32_t first_index_add = s_base[1] + a.first_index_base;
+  const uint32_t first_index_add = base_sum + a.first_index_base;
   uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
   const uint32_t words = tile_count * kCmdWords;
-  for (uint32_t j = tid; j < words; j += kTile) {
+  for (uint32_t j = lane; j < words; j += 64u) {
     uint32_t v = s_cmd[j];
     if (j % kCmdWords == 2u) v += first_index_add;
     out[j] = v;
   }
-  if (wave == 0) bulk_stores();
+  bulk_stores();
   MIP_STAMP(5);
 }
 
@@ -580,7 +586,10 @@ struct MergeArgs {
   uint32_t n_chunks;
   uint32_t* out_cmds;
   uint32_t* out_count;  // [0] = commands, [1] = indices
+  uint32_t* error_flag; // host-mapped
 };
+
+constexpr uint32_t kErrChunkOverflow = 2u;
 
 constexpr uint32_t kMaxMergeChunks = 64;
 
@@ -588,11 +597,17 @@ __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeAr
   __shared__ uint32_t s_count_base[kMaxMergeChunks + 1], s_index_base[kMaxMergeChunks + 1];
   if (threadIdx.x == 0) {
     uint32_t c = 0, s = 0;
+    const uint32_t capacity = (uint32_t)((a.stride - 32u) / (kCmdWords * 4u));
     for (uint32_t k = 0; k < a.n_chunks; ++k) {
       const uint32_t* h = reinterpret_cast<const uint32_t*>(a.chunks + k * a.stride);
+      uint32_t count = h[0];
+      if (count > capacity) {  // the shard emitted more than the exchanged chunk holds
+        count = capacity;
+        if (blockIdx.x == 0) __hip_atomic_store(a.error_flag, kErrChunkOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       s_count_base[k] = c;
       s_index_base[k] = s;
-      c += h[0];
+      c += count;
       s += h[1];
     }
     s_count_base[a.n_chunks] = c;

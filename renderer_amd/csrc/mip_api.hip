@@ -99,8 +99,11 @@ int32_t check_device_error(MipContext* ctx) {
   const uint32_t e = *(volatile uint32_t*)ctx->h_error;
   if (e) {
     *(volatile uint32_t*)ctx->h_error = 0;
-    return fail(ctx, MIP_ERR_TIMEOUT,
-                "look-back wait expired (a predecessor tile never published); outputs invalid");
+    if (e & mip::kErrTimeout)
+      return fail(ctx, MIP_ERR_TIMEOUT,
+                  "prefix wait expired (an earlier tile never published); outputs invalid");
+    return fail(ctx, MIP_ERR_CAPACITY,
+                "a shard's draw list is longer than the exchanged chunk holds; merged list truncated");
   }
   return MIP_OK;
 }
@@ -172,8 +175,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     const size_t tiles_cap = tiles_for((uint32_t)cap);
     // smallest group the kernel may pick is 16 tiles (group_shift 4)
     ctx->groups_cap = (uint32_t)((tiles_cap + 15) / 16);
-    ctx->acc1_offset_words = (uint32_t)(tiles_cap * 2);
-    ctx->status_bytes = tiles_cap * 16 + (size_t)ctx->groups_cap * 2 * 8 * mip::kAccStrideWords;
+    ctx->acc1_offset_words = (uint32_t)((tiles_cap + 31) / 32 * 32);  // keep the accumulators 256-B aligned
+    ctx->status_bytes = (size_t)ctx->acc1_offset_words * 8 + (size_t)ctx->groups_cap * 2 * 8 * mip::kAccStrideWords;
     MIP_HIP(ctx, hipMalloc(&ctx->d_status, ctx->status_bytes));
     MIP_HIP(ctx, hipMemset(ctx->d_status, 0, ctx->status_bytes));  // epoch 0 is never used
     MIP_HIP(ctx, hipMalloc(&ctx->d_scalars, 64));
@@ -315,7 +318,7 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.n_tiles = tiles_for(n);
   a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
   if (a.cmds && n) {
-    if (ctx->status_dirty || ctx->epoch >= 0xfffffffeu) {
+    if (ctx->status_dirty || ctx->epoch >= mip::kMaxEpoch) {
       MIP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, ctx->status_bytes, ctx->stream));
       ctx->status_dirty = false;
       ctx->epoch = 0;
@@ -392,6 +395,7 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
   a.n_chunks = n_chunks;
   a.out_cmds = (uint32_t*)out_cmds;
   a.out_count = out_count;
+  a.error_flag = ctx->d_error;
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0 && !async;
   if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   // Sized for the payload the stride can hold: every thread moves ~8 words.
@@ -414,7 +418,7 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
     ctx->timings.last_merge_ms = ms;
     ctx->timings.total_merge_ms += ms;
   }
-  return MIP_OK;
+  return check_device_error(ctx);
 }
 
 const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "null context"; }

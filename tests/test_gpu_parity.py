@@ -198,3 +198,95 @@ def test_full_size_properties(ra, oracle_mod):
     assert np.array_equal(m[:, 3, :3], s["pos"])
     want = run_oracle(oracle_mod, s, threads=8)
     assert_parity(got, want, "1M")
+
+
+def _golden_files():
+    import glob
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    return sorted(glob.glob(os.path.join(here, "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_files(), ids=lambda p: p.split("/")[-1])
+def test_golden_fixtures(ra, path):
+    """The committed vectors (inputs + oracle outputs) reproduce on the GPU without the oracle."""
+    g = np.load(path)
+    s = dict(pos=g["pos"], rot=g["rot"], scale=g["scale"], mesh_id=g["mesh_id"], meshes=g["meshes"],
+             planes=g["planes"], cam_pos=g["cam_pos"], n=len(g["scale"]))
+    got = run_gpu(ra, s, first_instance_base=int(g["first_instance_base"]), first_index_base=int(g["first_index_base"]))
+    want = dict(visible_bitmap=g["visible_bitmap"], draw_count=int(g["draw_count"]), draw_cmds=g["draw_cmds"],
+                draw_index_total=int(g["draw_index_total"]), model=g["model"], world_aabb=g["world_aabb"])
+    assert_parity(got, want, path)
+
+
+def test_merge_draw_lists_on_device(ra, oracle_mod):
+    """Three shards (one empty) computed on this GPU, laid out as an all-gather would, merged by
+    the device kernel == the unsharded oracle run; an undersized chunk is reported, not cut."""
+    import torch
+
+    from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
+    from renderer_amd.sharded import chunk_stride_bytes
+
+    s = ra.scene.make_scene(3, n=50_000)
+    spans = [(0, 17_000), (17_000, 17_000), (17_000, 50_000)]
+    cap = max(hi - lo for lo, hi in spans)
+    stride = chunk_stride_bytes(cap)
+    dev = torch.device("cuda", 0)
+    recv = torch.zeros(len(spans) * stride // 4, dtype=torch.int32, device=dev)
+    with ra.InstancePipeline(max_instances=cap, max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        for k, (lo, hi) in enumerate(spans):
+            p.set_instances(s["pos"][lo:hi], s["rot"][lo:hi], s["scale"][lo:hi], s["mesh_id"][lo:hi])
+            base = recv.data_ptr() + k * stride
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=lo),
+                         draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4)
+        merged = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+        count = torch.zeros(2, dtype=torch.int32, device=dev)
+        p.merge_draw_lists(recv.data_ptr(), len(spans), stride, merged.data_ptr(), count.data_ptr())
+        want = run_oracle(oracle_mod, s, threads=8)
+        total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
+        assert total == want["draw_count"] and index_total == want["draw_index_total"]
+        got = merged[:total].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+        assert got.tobytes() == want["draw_cmds"].tobytes()
+        # a stride too small for shard 2's list must raise MIP_ERR_CAPACITY
+        small = chunk_stride_bytes(64)
+        with pytest.raises(ra.MipError) as e:
+            p.merge_draw_lists(recv.data_ptr(), 1, small, merged.data_ptr(), count.data_ptr())
+        assert e.value.code == -4
+
+
+def test_exchange_step_world_size_one(ra, oracle_mod):
+    """The real frame driver (kernel -> all_gather_into_tensor over RCCL -> merge) with one rank."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from renderer_amd.sharded import DrawListExchange, make_shard_frame
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s = ra.scene.make_scene(3, n=300_000)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, stream=st.cuda_stream) as p:
+                p.set_mesh_table(s["meshes"])
+                p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+                ex = DrawListExchange(p, s["n"], 1, 0, dev)
+                frame = make_shard_frame(s["planes"], s["cam_pos"], s["n"], 1, 0)
+                ex.step(frame)
+                p.wait()
+                ex.tighten()
+                for _ in range(3):
+                    ex.step(frame)
+                p.wait()
+                cmds, total, index_total = ex.merged_draw_list()
+        want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+        assert total == want["draw_count"] and index_total == want["draw_index_total"]
+        assert cmds.tobytes() == want["draw_cmds"].tobytes()
+    finally:
+        dist.destroy_process_group()

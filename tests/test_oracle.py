@@ -1,0 +1,209 @@
+"""CPU tests of the oracle: committed golden vectors, hand-computable known answers, edge
+cases, and an independent numpy restatement. No GPU involved."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import numpy_restatement as npr
+from helpers import same_floats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def _scene_from(g):
+    return dict(pos=g["pos"], rot=g["rot"], scale=g["scale"], mesh_id=g["mesh_id"], meshes=g["meshes"],
+                planes=g["planes"], cam_pos=g["cam_pos"], n=len(g["scale"]))
+
+
+def _inside_planes():
+    """Six planes nothing is outside of: (0,0,0,-1) gives s = -1, e = 0."""
+    return np.tile(np.array([0, 0, 0, -1], np.float32), 6)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_golden(oracle_mod, path):
+    g = np.load(path)
+    s = _scene_from(g)
+    for threads in (None, 3):
+        r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"],
+                           first_instance_base=int(g["first_instance_base"]), first_index_base=int(g["first_index_base"]),
+                           threads=threads)
+        assert np.array_equal(r["visible_bitmap"], g["visible_bitmap"])
+        assert np.array_equal(r["coarse_culled"], g["coarse_culled"])
+        assert r["draw_count"] == int(g["draw_count"]) and r["draw_index_total"] == int(g["draw_index_total"])
+        assert r["draw_cmds"].tobytes() == g["draw_cmds"].tobytes()
+        assert same_floats(r["model"], g["model"]) and same_floats(r["world_aabb"], g["world_aabb"])
+
+
+def test_golden_set_is_present():
+    names = {os.path.basename(p) for p in GOLDEN}
+    assert {"box_1024.npz", "special_513.npz", "mixed_4097_bases.npz"} <= names
+
+
+def test_model_matrix_known_answers(oracle_mod):
+    # identity rotation, unit scale: M = T
+    m = oracle_mod.model_matrix([1, 2, 3], [0, 0, 0, 1], 1.0).reshape(4, 4).T
+    assert np.array_equal(m, np.array([[1, 0, 0, 1], [0, 1, 0, 2], [0, 0, 1, 3], [0, 0, 0, 1]], np.float32))
+    # 90 degrees about +Y (q = (0, sqrt(.5), 0, sqrt(.5))), scale 2: z -> x
+    r = np.float32(np.sqrt(0.5))
+    m = oracle_mod.model_matrix([0, 0, 0], [0, r, 0, r], 2.0).reshape(4, 4).T
+    two_wj = np.float32(np.float32(r * r) * np.float32(2.0)) * np.float32(2.0)  # (w*j*2)*s
+    assert m[0, 2] == two_wj and m[2, 0] == -two_wj and m[1, 1] == np.float32(np.float32(r * r) + np.float32(r * r)) * 2
+    assert m[0, 0] == 0 and m[2, 2] == 0 and np.array_equal(m[3], [0, 0, 0, 1])
+    # the quaternion is not renormalised: |q| = 2 scales the rotation block by 4
+    m = oracle_mod.model_matrix([0, 0, 0], [0, 0, 0, 2], 1.0).reshape(4, 4).T
+    assert np.array_equal(np.diag(m), [4, 4, 4, 1])
+    # zero scale collapses the linear part, translation survives
+    m = oracle_mod.model_matrix([5, 6, 7], [0.1, 0.2, 0.3, 0.9], 0.0).reshape(4, 4).T
+    assert np.all(m[:3, :3] == 0) and np.array_equal(m[:3, 3], [5, 6, 7])
+
+
+def test_world_aabb_roundtrip_and_nan_fold(oracle_mod):
+    m = oracle_mod.model_matrix([10, 0, 0], [0, 0, 0, 1], 2.0)
+    mins, maxs = oracle_mod.world_aabb(m, [-0.5, -1, -2], [0.5, 1, 2])
+    assert np.array_equal(mins, [9, -2, -4]) and np.array_equal(maxs, [11, 2, 4])
+    # all corners NaN: f32::min/max ignore NaN, so the fold keeps (MAX, MIN); centre 0, half -inf
+    m = oracle_mod.model_matrix([np.nan, np.nan, np.nan], [0, 0, 0, 1], 1.0)
+    mins, maxs = oracle_mod.world_aabb(m, [-1, -1, -1], [1, 1, 1])
+    assert np.all(np.isposinf(mins)) and np.all(np.isneginf(maxs))
+
+
+def test_plane_tangency_is_visible(oracle_mod):
+    planes = _inside_planes()
+    planes[0:4] = [1, 0, 0, -5]  # outside where x - 5 > 0
+    one_up = np.nextafter(np.float32(6), np.float32(7))
+    for cx, want_culled in ((4.0, False), (6.0, False), (one_up, True), (7.0, True)):
+        mins = np.array([cx - 1, -1, -1], np.float32)
+        maxs = np.array([cx + 1, 1, 1], np.float32)
+        # at cx = 6 the box spans [5, 7]: s - e = (6 - 5) - 1 = 0, not > 0
+        assert oracle_mod.coarse_culled(mins, maxs, planes) == want_culled, cx
+    # NaN box => every comparison false => visible
+    assert oracle_mod.coarse_culled([np.nan] * 3, [np.nan] * 3, planes) is False
+
+
+def test_default_camera_planes(oracle_mod):
+    from renderer_amd import scene
+
+    planes = scene.default_planes()
+    committed = np.load(os.path.join(HERE, "golden", "default_planes.npy"))
+    assert np.array_equal(planes, committed)
+    # the oracle's float32 project_camera agrees with the float64-rounded planes to a few ulp
+    assert np.allclose(oracle_mod.project_camera(), planes, rtol=2e-6, atol=1e-6)
+    p = planes.reshape(6, 4)
+
+    def outside(pt):
+        return [float(np.dot(pl[:3], pt) + pl[3]) > 0 for pl in p]
+
+    assert not any(outside([0, 1, 12]))           # straight ahead
+    assert outside([0, 1, 1.0])[4]                # nearer than the (GL-style, conservative) near plane
+    assert outside([0, 1, 103.0])[5]              # beyond far = 100 from z = 2
+    assert outside([-100, 1, 12])[0] and outside([100, 1, 12])[1]
+    assert outside([0, -100, 12])[2] and outside([0, 100, 12])[3]
+
+
+def test_pick_lod_threshold(oracle_mod):
+    cam = np.array([0, 1, 2], np.float32)
+    assert oracle_mod.pick_lod(3, cam, [0, 1, 12]) == 0          # distance exactly 10: `>` is false
+    assert oracle_mod.pick_lod(3, cam, [0, 1, np.nextafter(np.float32(12), np.float32(13))]) == 1
+    assert oracle_mod.pick_lod(1, cam, [0, 1, 500]) == 0         # a single LOD never switches
+    assert oracle_mod.pick_lod(3, cam, [np.nan, 1, 12]) == 0     # NaN distance: comparison false
+
+
+def test_lod_squared_distance_threshold_equivalence():
+    """The kernel tests dist^2 > 100 + 2^-17 instead of sqrt(dist^2) > 10 (kLodDistSqThreshold):
+    equivalent for every float because sqrt is correctly rounded and monotonic."""
+    thr = np.float32(100.00000762939453125)
+    assert thr == np.nextafter(np.float32(100), np.float32(101))
+    lo, hi = np.float32(99.5).view(np.uint32), np.float32(100.5).view(np.uint32)
+    q = np.arange(lo, hi + 1, dtype=np.uint32).view(np.float32)  # every float in [99.5, 100.5]
+    assert len(q) > 100_000
+    assert np.array_equal(np.sqrt(q) > np.float32(10.0), q > thr)
+    for special in (np.float32(np.inf), np.float32(np.nan), np.float32(0), np.float32(3.4e38), np.float32(1e-45)):
+        with np.errstate(invalid="ignore"):
+            assert bool(np.sqrt(special) > np.float32(10.0)) == bool(special > thr)
+
+
+def test_emit_and_compact_semantics(oracle_mod):
+    from renderer_amd import scene
+
+    s = scene.make_scene(3, n=3000, all_visible=True)
+    s["meshes"]["index_len"][::5, 0] = 0
+    s["meshes"]["index_len"][::5, 1] = 0
+    r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"],
+                       first_instance_base=7, first_index_base=100)
+    cmds = r["draw_cmds"]
+    vis = r["coarse_culled"] == 0
+    assert vis.all()
+    assert np.all(cmds["indexCount"] > 0) and np.all(cmds["instanceCount"] == 1)
+    assert np.all(np.diff(cmds["firstInstance"].astype(np.int64)) > 0)  # stable order
+    dropped = s["n"] - len(cmds)
+    assert dropped == int((s["meshes"]["index_len"][s["mesh_id"], 0] == 0).sum()) > 0
+    run = 100 + np.concatenate([[0], np.cumsum(cmds["indexCount"].astype(np.int64))[:-1]])
+    assert np.array_equal(cmds["firstIndex"].astype(np.int64), run)
+    assert np.array_equal(cmds["vertexOffset"], s["meshes"]["vertex_offset"][s["mesh_id"][cmds["firstInstance"] - 7]])
+    # compaction on its own: zero entries vanish, order kept, in-place capable
+    sparse = np.zeros(10, oracle_mod.DRAW_CMD_DTYPE)
+    sparse["indexCount"][[1, 4, 9]] = (3, 6, 9)
+    sparse["firstInstance"] = np.arange(10)
+    packed = oracle_mod.compact_draw_stream(sparse)
+    assert packed["firstInstance"].tolist() == [1, 4, 9]
+
+
+def test_first_index_wraps_like_u32(oracle_mod):
+    from renderer_amd import scene
+
+    s = scene.make_scene(2, n=200_000, all_visible=True)  # 200k x 46 356 indices overflows 2^32
+    r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=8,
+                       want=("draw_cmds",))
+    total = int(r["draw_cmds"]["indexCount"].astype(np.uint64).sum())
+    assert total > 2 ** 32 and r["draw_index_total"] == total % 2 ** 32
+
+
+def test_merge_draw_lists(oracle_mod):
+    from renderer_amd import scene
+
+    s = scene.make_scene(3, n=5000)
+    whole = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])
+    lists, totals = [], []
+    for lo, hi in ((0, 1700), (1700, 1700), (1700, 5000)):  # includes an empty shard
+        part = oracle_mod.run(s["pos"][lo:hi], s["rot"][lo:hi], s["scale"][lo:hi], s["mesh_id"][lo:hi], s["meshes"],
+                              s["planes"], s["cam_pos"], first_instance_base=lo)
+        lists.append(part["draw_cmds"])
+        totals.append(part["draw_index_total"])
+    merged, index_total = oracle_mod.merge_draw_lists(lists, totals)
+    assert merged.tobytes() == whole["draw_cmds"].tobytes() and index_total == whole["draw_index_total"]
+
+
+@pytest.mark.parametrize("special", [False, True])
+def test_numpy_restatement_agrees(oracle_mod, special):
+    from renderer_amd import scene
+
+    s = scene.make_scene(3, n=20_000, all_visible=special)
+    if special:
+        rng = np.random.default_rng(3)
+        sv = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 1e-38, 3.4e38, -3.4e38, 1e19, 1e-20], np.float32)
+        for col, width in (("pos", 3), ("rot", 4)):
+            rows = rng.choice(s["n"], 500, replace=False)
+            s[col][rows, rng.integers(0, width, 500)] = rng.choice(sv, 500)
+        s["scale"][rng.choice(s["n"], 300, replace=False)] = rng.choice(sv, 300)
+    a = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])
+    b = npr.run(s)
+    assert same_floats(a["model"], b["model"])
+    assert same_floats(a["world_aabb"], b["world_aabb"])
+    assert np.array_equal(a["coarse_culled"].astype(bool), b["coarse_culled"])
+    c = a["draw_cmds"]
+    assert np.array_equal(c["indexCount"], b["cmds"]["indexCount"]) and np.array_equal(c["firstIndex"], b["cmds"]["firstIndex"])
+    assert np.array_equal(c["firstInstance"], b["cmds"]["firstInstance"]) and np.array_equal(c["vertexOffset"], b["cmds"]["vertexOffset"])
+    assert a["draw_index_total"] == b["cmds"]["total"]
+
+
+def test_mesh_id_out_of_range_is_rejected(oracle_mod):
+    from renderer_amd import scene
+
+    s = scene.make_scene(1, n=8)
+    s["mesh_id"][3] = 9
+    with pytest.raises(ValueError):
+        oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])

@@ -1,0 +1,77 @@
+"""World-size-2 (and 3) gloo test of the N>1 path on CPU: contiguous shards, one all-gather of
+the fixed-size draw-list chunks, merge with firstIndex rebasing == the unsharded oracle run."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, init_file, n_global, tighten, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle
+    from cpu_pipeline import OraclePipeline
+    from renderer_amd import scene
+    from renderer_amd.sharded import DrawListExchange, make_shard_frame, shard_range
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        full = scene.make_scene(3, n=n_global)
+        lo, hi = shard_range(n_global, world, rank)
+        # the shard is regenerated from the stream position, exactly as a rank would do it
+        shard = scene.make_scene(3, n=hi - lo, first=lo)
+        assert np.array_equal(shard["pos"], full["pos"][lo:hi])
+        pipe = OraclePipeline(shard)
+        n_local = hi - lo
+        ex = DrawListExchange(pipe, n_local, world, rank, torch.device("cpu"), dist=dist, torch=torch)
+        frame = make_shard_frame(full["planes"], full["cam_pos"], n_global, world, rank)
+        bitmap = torch.zeros((n_local + 31) // 32 + 1, dtype=torch.int32)
+        model = torch.zeros((max(n_local, 1), 16), dtype=torch.float32)
+        ex.step(frame, model=model.data_ptr(), visible_bitmap=bitmap.data_ptr())
+        if tighten:
+            cap = ex.tighten()
+            assert cap <= max(n_local, 256)
+            ex.step(frame, model=model.data_ptr(), visible_bitmap=bitmap.data_ptr())
+        cmds, total, index_total = ex.merged_draw_list()
+        want = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], full["planes"],
+                          full["cam_pos"])
+        assert total == want["draw_count"], (total, want["draw_count"])
+        assert cmds.tobytes() == want["draw_cmds"].tobytes()
+        assert index_total == want["draw_index_total"]
+        # the sharded outputs stay sharded: this rank's matrices/bitmap are its slice of the global ones
+        assert np.array_equal(model.numpy()[:n_local], want["model"][lo:hi])
+        vis_local = np.unpackbits(bitmap.numpy()[: (n_local + 31) // 32].view(np.uint8), bitorder="little")[:n_local]
+        vis_global = np.unpackbits(want["visible_bitmap"].view(np.uint8), bitorder="little")[lo:hi]
+        assert np.array_equal(vis_local, vis_global)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_global,tighten", [(2, 20_000, False), (2, 4_097, True), (3, 1_000, True), (2, 1, False)])
+def test_sharded_exchange_matches_unsharded_oracle(world, n_global, tighten):
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, init_file, n_global, tighten, d), nprocs=world, join=True)
+        for r in range(world):
+            assert os.path.exists(os.path.join(d, f"ok{r}"))
+
+
+def test_shard_ranges_cover_everything():
+    from renderer_amd.sharded import chunk_stride_bytes, shard_range
+
+    for n in (0, 1, 7, 8, 9, 1000, 10_000_000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, e) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= e
+    assert chunk_stride_bytes(0) == 256 and chunk_stride_bytes(12) % 256 == 0

@@ -1,0 +1,30 @@
+#!/bin/bash
+# PMC passes (one counter group per run, no tracing domains besides kernel-trace).
+# usage: tools/pmc.sh <tag> <config>
+TAG=${1:-r01}; CFG=${2:-3}
+OUT=$(pwd)/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$(pwd)
+cd /tmp
+for v in full no_cmds bitmap_only model_only; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${v}_$c -- python3 $ROOT/tools/pmc_run.py $v $CFG 10 > $OUT/${v}_$c.log 2>&1
+  done
+done
+cd $ROOT
+python3 - <<PY
+import csv, glob, collections
+out="$OUT"
+for v in ("full","no_cmds","bitmap_only","model_only"):
+    row={}
+    for c in ("FETCH_SIZE","WRITE_SIZE"):
+        fs=glob.glob(f"{out}/{v}_{c}/**/*counter_collection.csv", recursive=True)
+        vals=[]
+        for f in fs:
+            for r in csv.DictReader(open(f)):
+                if "mip_instance" in r["Kernel_Name"] and r["Counter_Name"]==c:
+                    vals.append(float(r["Counter_Value"]))
+        row[c]=(sum(vals)/len(vals) if vals else float("nan"), len(vals))
+    print(v, {k:(round(a,1),n) for k,(a,n) in row.items()})
+PY
