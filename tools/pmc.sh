@@ -16,6 +16,11 @@ cd $ROOT
 python3 - <<PY
 import csv, glob, collections
 out="$OUT"
+import json, sys
+sys.path.insert(0, "$ROOT")
+from renderer_amd import scene
+cfg=$CFG
+rows=[]
 for v in ("full","no_cmds","bitmap_only","model_only"):
     row={}
     for c in ("FETCH_SIZE","WRITE_SIZE"):
@@ -27,4 +32,9 @@ for v in ("full","no_cmds","bitmap_only","model_only"):
                     vals.append(float(r["Counter_Value"]))
         row[c]=(sum(vals)/len(vals) if vals else float("nan"), len(vals))
     print(v, {k:(round(a,1),n) for k,(a,n) in row.items()})
+    f,w=row["FETCH_SIZE"][0],row["WRITE_SIZE"][0]
+    rows.append(dict(config=cfg, instances=scene.CONFIGS[cfg]["n"], variant=v, launches=row["FETCH_SIZE"][1],
+                     FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
+                     fetch_bytes_corrected=2*f*1024, write_bytes=w*1024, hbm_bytes_per_launch=2*f*1024+w*1024))
+json.dump(dict(note="rocprofv3 --pmc, one counter per pass; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md HBM section; calibrated here: bitmap_only reads 36 B/instance), WRITE_SIZE exact", workloads=rows), open(f"{out}/pmc_summary.json","w"), indent=1)
 PY
