@@ -63,6 +63,7 @@ struct KernelArgs {
   float* world_aabb;            // n*6 or null
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
+  unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
   uint32_t groups_cap;
   uint32_t group_shift;         // log2(tiles per group), <= 6
   uint32_t* error_flag;         // host-mapped
@@ -290,7 +291,12 @@ __device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&p
 //                            the first tile of each group; the host clears everything
 //                            whenever the instance count changes or the tag wraps.
 //
-//   prefix(tile) = Σ acc1[g' < g]  +  Σ status0[first tile of g .. tile-1]
+//            start1[g]       {epoch : 32 | count : 32} {epoch : 32 | Σ index_len : 32}: the exclusive
+//                            prefix at the start of group g, published by the group's first
+//                            tile when it has resolved its own prefix (a by-product).
+//
+//   prefix(tile) = start1[g_lo] + Σ acc1[g_lo .. g-1] + Σ status0[first tile of g .. tile-1],
+//   g_lo = max(0, g - 64)
 //
 // No payload is handed off behind these words (every tile writes its own commands), so no
 // release/acquire fence is involved; readers use relaxed agent-scope atomic loads (sc1).
@@ -299,7 +305,6 @@ constexpr uint32_t kAccCountBits = 20, kAccArrivalBits = 12;
 // Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
 // words would put all of that traffic (and the atomics) on one or two memory channels.
 constexpr uint32_t kAccStrideWords = 32;
-constexpr uint32_t kLevel1Unroll = 2;  // level-1 words each lane keeps in flight per round
 constexpr uint32_t kTagBits = 23, kTileCountBits = 9;
 constexpr uint32_t kMaxEpoch = (1u << kTagBits) - 1u;
 static_assert(kTile < (1u << kTileCountBits), "tile count must fit its field");
@@ -321,79 +326,83 @@ __device__ __forceinline__ void publish_aggregate(const KernelArgs& a, uint32_t 
 }
 
 constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz realtime counter
+constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
 
-// Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`.
+// Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`:
+//   prefix = start1[g_lo]  +  Σ acc1[g_lo .. g-1]  +  Σ status0[first tile of g .. tile-1]
+// with g_lo = max(0, g - 64). start1[g] (the exclusive prefix at the start of group g) is
+// published for free by the first tile of group g once it has resolved its own prefix; the
+// entry read here is 64 groups = thousands of tiles back, i.e. long resolved, so the look-up
+// stays ONE round of <= 63 + 64 + 1 words for any N (without it every tile would read every
+// earlier group: quadratic, measured +100 us at 10 M instances).
 __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t tile, uint32_t lane,
                                                uint32_t& base_count, uint32_t& base_sum) {
   const uint32_t group = tile >> a.group_shift;
   const uint32_t group_first = group << a.group_shift;
   const uint32_t r = tile - group_first;  // earlier tiles of the own group (< 64)
   const uint32_t per_group = 1u << a.group_shift;
+  const uint32_t g_lo = group > kLevel1Window ? group - kLevel1Window : 0u;
   const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  uint32_t c_total = 0, s_total = 0;
   bool ok = true;
 
   // level 0: lane l < r reads the aggregate of tile group_first + l
   const bool v0 = lane < r;
   const unsigned long long* e0 = &a.status0[group_first + (v0 ? lane : 0u)];
-  bool ready0 = !v0;
-  uint32_t c0 = 0, s0 = 0;
+  // level 1: lane l reads the accumulator of group g_lo + l
+  const bool v1 = g_lo + lane < group;
+  const unsigned long long* e1 = &acc[(size_t)(g_lo + (v1 ? lane : 0u)) * kAccStrideWords];
+  // far prefix: lane 0 reads the two granules of start1[g_lo]
+  const bool v2 = g_lo > 0u && lane == 0u;
+  const unsigned long long* e2 = &a.start1[2 * (size_t)g_lo];
 
-  for (uint32_t g0 = 0; ok && (g0 < group || g0 == 0u); g0 += 64u * kLevel1Unroll) {
-    bool ready1[kLevel1Unroll];
-    uint32_t c1[kLevel1Unroll], s1[kLevel1Unroll];
-#pragma unroll
-    for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
-      ready1[k] = !(g0 + 64u * k + lane < group);
-      c1[k] = 0;
-      s1[k] = 0;
+  bool ready0 = !v0, ready1 = !v1, ready2 = !v2;
+  uint32_t c = 0, s = 0;
+  for (;;) {
+    if (!ready0) {
+      const unsigned long long g = status_load(e0);
+      if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
+        ready0 = true;
+        c += (uint32_t)g & ((1u << kTileCountBits) - 1u);
+        s += (uint32_t)(g >> 32);
+      }
     }
-    for (;;) {
-      bool all = ready0;
-      if (!ready0) {
-        const unsigned long long g = status_load(e0);
-        if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
-          ready0 = true;
-          c0 = (uint32_t)g & ((1u << kTileCountBits) - 1u);
-          s0 = (uint32_t)(g >> 32);
-        }
-        all = ready0;
+    if (!ready1) {
+      const unsigned long long w = status_load(e1);
+      if (((uint32_t)w >> kAccCountBits) == per_group) {  // every tile of that group has added
+        ready1 = true;
+        c += (uint32_t)w & ((1u << kAccCountBits) - 1u);
+        s += (uint32_t)(w >> 32);
       }
-#pragma unroll
-      for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
-        if (!ready1[k]) {
-          const unsigned long long w = status_load(&acc[(size_t)(g0 + 64u * k + lane) * kAccStrideWords]);
-          if (((uint32_t)w >> kAccCountBits) == per_group) {  // every tile of that group has added
-            ready1[k] = true;
-            c1[k] = (uint32_t)w & ((1u << kAccCountBits) - 1u);
-            s1[k] = (uint32_t)(w >> 32);
-          }
-        }
-        all = all && ready1[k];
+    }
+    if (!ready2) {
+      const unsigned long long pc = status_load(e2), ps = status_load(e2 + 1);
+      if ((uint32_t)(pc >> 32) == a.epoch && (uint32_t)(ps >> 32) == a.epoch) {
+        ready2 = true;
+        c += (uint32_t)pc;
+        s += (uint32_t)ps;
       }
+    }
+    const bool all = ready0 && ready1 && ready2;
 #ifdef MIP_DEBUG_STAMPS
-      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
-      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
-      if (__all(all)) break;
-      if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
+    if (__all(all)) break;
+    if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
+      ok = false;
+      break;
     }
-#pragma unroll
-    for (uint32_t k = 0; k < kLevel1Unroll; ++k) {
-      c_total += c1[k];
-      s_total += s1[k];
-    }
+    __builtin_amdgcn_s_sleep(1);
   }
-  c_total += c0;
-  s_total += s0;
   if (ok) {
-    base_count = wave_sum(c_total);
-    base_sum = wave_sum(s_total);
+    base_count = wave_sum(c);
+    base_sum = wave_sum(s);
+    if (r == 0u && group > 0u && lane == 0u) {  // first tile of a group: publish the group's start
+      unsigned long long* p = &a.start1[2 * (size_t)group];
+      __hip_atomic_store(p, ((unsigned long long)a.epoch << 32) | base_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p + 1, ((unsigned long long)a.epoch << 32) | base_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     if (lane == 0) __hip_atomic_store(a.error_flag, kErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     base_count = 0;
@@ -408,7 +417,11 @@ __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t til
 __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pipeline_kernel(const KernelArgs a) {
   __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
   __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
-  __shared__ __attribute__((aligned(16))) uint32_t s_cmd[kTile * kCmdWords];
+  // The tile's commands (5 KB) reuse the staging area of waves 1-3 (9 KB) once those waves have
+  // stored their matrices: 13.6 KB of LDS per workgroup instead of 18.5 KB, so that more
+  // workgroups whose wave 0 is still waiting for its prefix fit beside the running ones.
+  uint32_t* const s_cmd = reinterpret_cast<uint32_t*>(&s_mat[64 * 12]);
+  static_assert((kTile - 64) * 12 >= kTile * kCmdWords, "commands must fit the staging area of waves 1-3");
   __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -534,6 +547,9 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
     return;
   }
 
+  if (wave != 0) bulk_stores();
+  __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
+
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
     uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdWords];
@@ -546,13 +562,9 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   __syncthreads();  // s_cmd complete
   MIP_STAMP(3);
 
-  // Waves 1-3 are finished once their stores are issued: they exit and free their
-  // registers and wave slots for the next workgroup while wave 0 alone waits for the
-  // tile's prefix and copies the commands out.
-  if (wave != 0) {
-    bulk_stores();
-    return;
-  }
+  // Waves 1-3 are finished: they exit and free their registers and wave slots for the next
+  // workgroup while wave 0 alone waits for the tile's prefix and copies the commands out.
+  if (wave != 0) return;
 
   // ---- exclusive prefix over the earlier tiles, before any bulk store of this wave ----
   uint32_t base_count = 0, base_sum = 0;

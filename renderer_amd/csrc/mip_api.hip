@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -37,9 +38,10 @@ struct MipContext {
   // look-back state
   unsigned long long* d_status = nullptr;  // level-0 entries, then 2 x groups_cap accumulators
   size_t status_bytes = 0;
-  uint32_t acc1_offset_words = 0, groups_cap = 0;
+  uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t epoch = 0;
-  bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
+  bool status_dirty = false;
+  uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU  // instance count changed: clear the prefix state before the next launch
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   uint32_t* d_scalars = nullptr;  // [0] draw_count, [1] index_total, [2..3] merge out
@@ -176,7 +178,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     // smallest group the kernel may pick is 16 tiles (group_shift 4)
     ctx->groups_cap = (uint32_t)((tiles_cap + 15) / 16);
     ctx->acc1_offset_words = (uint32_t)((tiles_cap + 31) / 32 * 32);  // keep the accumulators 256-B aligned
-    ctx->status_bytes = (size_t)ctx->acc1_offset_words * 8 + (size_t)ctx->groups_cap * 2 * 8 * mip::kAccStrideWords;
+    ctx->start1_offset_words = ctx->acc1_offset_words + ctx->groups_cap * 2 * mip::kAccStrideWords;
+    ctx->status_bytes = ((size_t)ctx->start1_offset_words + (size_t)ctx->groups_cap * 2) * 8;
     MIP_HIP(ctx, hipMalloc(&ctx->d_status, ctx->status_bytes));
     MIP_HIP(ctx, hipMemset(ctx->d_status, 0, ctx->status_bytes));  // epoch 0 is never used
     MIP_HIP(ctx, hipMalloc(&ctx->d_scalars, 64));
@@ -188,6 +191,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMalloc(&ctx->d_stamps, tiles_cap * 64));
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
+    if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
     MIP_HIP(ctx, hipEventCreate(&ctx->ev1));
     return MIP_OK;
@@ -300,6 +304,7 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
   a.status0 = ctx->d_status;
   a.acc1 = ctx->d_status + ctx->acc1_offset_words;
+  a.start1 = ctx->d_status + ctx->start1_offset_words;
   a.groups_cap = ctx->groups_cap;
   a.error_flag = ctx->d_error;
   a.n = n;
@@ -332,7 +337,7 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, ctx->stream));
   } else {
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), 0, ctx->stream, a);
+    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, ctx->stream, a);
     MIP_HIP(ctx, hipGetLastError());
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   }

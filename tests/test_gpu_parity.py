@@ -290,3 +290,11 @@ def test_exchange_step_world_size_one(ra, oracle_mod):
         assert cmds.tobytes() == want["draw_cmds"].tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def test_three_million_instances_multi_window_prefix(ra, oracle_mod):
+    """> 2 M instances needs more than one round of level-1 accumulator reads per tile."""
+    s = ra.scene.make_scene(4, n=3_000_000)
+    got = run_gpu(ra, s, want=("visible_bitmap", "draw_cmds"))
+    want = run_oracle(oracle_mod, s, threads=8, want=("visible_bitmap", "draw_cmds"))
+    assert_parity(got, want, "3M")
