@@ -77,6 +77,7 @@ struct KernelArgs {
   float cam[3];
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
+  uint32_t debug_skip_publish_tile;  // diagnostic build only: tile index + 1 that never publishes (0 = off)
 #endif
 };
 
@@ -501,7 +502,14 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   }
 
   const bool want_cmds = a.cmds != nullptr;
-  if (want_cmds && tid == 0) publish_aggregate(a, tile, tile_count, tile_sum);
+#ifdef MIP_DEBUG_STAMPS
+  // fault injection (diagnostic build only): one tile never publishes, so every later tile's
+  // bounded wait must expire and the launch must end with MIP_ERR_TIMEOUT instead of hanging
+  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
+#else
+  const bool skip_publish = false;
+#endif
+  if (want_cmds && tid == 0 && !skip_publish) publish_aggregate(a, tile, tile_count, tile_sum);
   MIP_STAMP(2);
 
   // Bulk stores of this wave: matrices, visibility words, optional AABBs. Wave 0 issues

@@ -315,6 +315,7 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
 #ifdef MIP_DEBUG_STAMPS
   a.stamps = ctx->d_stamps;
+  if (const char* env = std::getenv("MIP_DEBUG_SKIP_PUBLISH_TILE")) a.debug_skip_publish_tile = (uint32_t)std::atoi(env) + 1u;
 #endif
 
   // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh epoch per launch

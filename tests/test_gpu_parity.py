@@ -298,3 +298,42 @@ def test_three_million_instances_multi_window_prefix(ra, oracle_mod):
     got = run_gpu(ra, s, want=("visible_bitmap", "draw_cmds"))
     want = run_oracle(oracle_mod, s, threads=8, want=("visible_bitmap", "draw_cmds"))
     assert_parity(got, want, "3M")
+
+
+def test_bounded_wait_ends_a_stuck_launch_with_an_error():
+    """Fault injection (diagnostic build): tile 5 never publishes its aggregate. Every later tile
+    depends on it; the bounded in-kernel wait must expire (0.5 s), the launch must finish, and the
+    ABI must report MIP_ERR_TIMEOUT instead of hanging the GPU. The context stays usable."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
+    code = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
+os.environ["MIP_DEBUG_SKIP_PUBLISH_TILE"] = "5"
+import renderer_amd
+from renderer_amd import scene
+s = scene.make_scene(3, n=8192)
+p = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]))
+p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+t0 = time.time()
+try:
+    p.run_host(s["planes"], s["cam_pos"])
+    print("NOERROR")
+except renderer_amd.MipError as e:
+    print("CODE", e.code, "%.2f" % (time.time() - t0))
+del os.environ["MIP_DEBUG_SKIP_PUBLISH_TILE"]
+r = p.run_host(s["planes"], s["cam_pos"])   # the same context recovers on the next frame
+print("RECOVERED", r["draw_count"])
+'''
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split("\n")
+    code_line = [l for l in lines if l.startswith("CODE")]
+    assert code_line and code_line[0].split()[1] == "-7", out.stdout  # MIP_ERR_TIMEOUT
+    assert float(code_line[0].split()[2]) < 10.0
+    assert any(l.startswith("RECOVERED") and int(l.split()[1]) > 0 for l in lines), out.stdout
