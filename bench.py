@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="frames the host keeps in flight (own output buffers each), as the reference's "
+                         "per-swapchain-image buffers allow; 1 = strictly serialized steps")
     return ap.parse_args()
 
 
@@ -188,35 +191,44 @@ def main():
     n_global = n_local * world
     s = scene.make_scene(args.config, n=n_local, first=rank * n_local, all_visible=args.all_visible)
 
-    # The context enqueues on a real (non-null) torch stream made current here, so that
-    # torch.cuda.Event and the NCCL ops are ordered with the kernels.
+    # Streams: the sharded path needs the kernels ordered with torch's NCCL ops, so there the
+    # context enqueues on a real (non-null) torch stream made current here. Otherwise the
+    # context owns one stream per frame in flight.
     torch_stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
-    pipe = renderer_amd.InstancePipeline(max_instances=n_local, max_meshes=len(s["meshes"]),
-                                         device=local_rank, stream=stream)
+    exchange_on = distributed and n_global >= ALLGATHER_MIN_INSTANCES
+    frames = 1 if exchange_on else max(1, args.frames_in_flight)
+    pipe = renderer_amd.InstancePipeline(max_instances=n_local, max_meshes=len(s["meshes"]), device=local_rank,
+                                         stream=stream if exchange_on else None, frames_in_flight=frames)
     pipe.set_mesh_table(s["meshes"])
     pipe.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-    outs = DeviceOutputs(torch, n_local, device)
+    out_sets = [DeviceOutputs(torch, n_local, device) for _ in range(frames)]  # one set per frame in flight
+    outs = out_sets[0]
     frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=rank * n_local)
+    torch.cuda.synchronize()
 
     exchange = None
-    if distributed and n_global >= ALLGATHER_MIN_INSTANCES:
+    if exchange_on:
         from renderer_amd.sharded import DrawListExchange
 
         exchange = DrawListExchange(pipe, n_local, world, rank, device)
 
     if exchange is None:
-        kw = outs.kwargs()
+        kws = [o.kwargs() for o in out_sets]
+        counter = [0]
 
         def step():
-            pipe.run_device(frame, async_=True, **kw)
+            k = counter[0]
+            counter[0] = (k + 1) % frames
+            pipe.run_device(frame, async_=True, **kws[k])
     else:
         def step():
             exchange.step(frame, outs)
 
-    # one checked run: visible fraction + sanity
-    step()
+    # one checked run per output set: visible fraction + sanity
+    for _ in range(frames):
+        step()
     torch.cuda.synchronize()
     pipe.wait()
     if exchange is None:
@@ -253,19 +265,32 @@ def main():
             "visible_fraction": visible / max(n_local, 1),
             "emitted_fraction": v_emit,
             "draw_list_exchange": "rccl all-gather + merge" if exchange is not None else "none (< 1 M instances or 1 GPU)",
+            "frames_in_flight": frames,
             "outputs": "model[N] mat4 + visibility bitmap + compacted VkDrawIndexedIndirectCommand stream, HBM-resident",
         },
     }
 
     if rank == 0:
-        # roofline of the dominant (only) kernel, measured with HIP events around each launch
+        # roofline of the dominant (only) kernel: one frame at a time on one stream (the kernel
+        # alone on the chip, which is also what the rocprofv3 trace in profiles/ shows)
+        if frames == 1 and exchange is None:
+            serial = pipe
+        else:
+            serial = renderer_amd.InstancePipeline(max_instances=n_local, max_meshes=len(s["meshes"]),
+                                                   device=local_rank, stream=stream)
+            serial.set_mesh_table(s["meshes"])
+            serial.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
         kw = outs.kwargs()
 
         def kernel_only():
-            pipe.run_device(frame, async_=True, **kw)
+            serial.run_device(frame, async_=True, **kw)
 
         kt = kernel_event_time(torch, kernel_only, max(args.steps, 50), args.warmup)
-        pipe.wait()
+        serial.wait()
+        result["serialized"] = {"ms_per_step": kt["mean"], "instances_per_s": n_local / (kt["mean"] * 1e-3),
+                                "note": "one frame in flight: every step waits for the previous one"}
+        if serial is not pipe:
+            serial.close()
         bytes_per_launch = n_local * algorithmic_bytes_per_instance(v_emit)
         achieved = bytes_per_launch / (kt["mean"] * 1e-3) / 1e9
         pmc = pmc_traffic(args.config, n_local) if not args.all_visible else None
@@ -294,29 +319,35 @@ def main():
         extra = {}
         for label, conf, allvis in (("mixed_1m", 3, False), ("mixed_1m_all_visible", 3, True)):
             s2 = scene.make_scene(conf, all_visible=allvis)
-            p2 = renderer_amd.InstancePipeline(max_instances=s2["n"], max_meshes=len(s2["meshes"]),
-                                               device=local_rank, stream=stream)
-            p2.set_mesh_table(s2["meshes"])
-            p2.set_instances(s2["pos"], s2["rot"], s2["scale"], s2["mesh_id"])
-            o2 = DeviceOutputs(torch, s2["n"], device)
             f2 = make_frame(s2["planes"], s2["cam_pos"])
-            kw2 = o2.kwargs()
+            row = {"instances": s2["n"]}
+            for nf in sorted({1, frames}):
+                p2 = renderer_amd.InstancePipeline(max_instances=s2["n"], max_meshes=len(s2["meshes"]),
+                                                   device=local_rank, stream=stream if nf == 1 else None,
+                                                   frames_in_flight=nf)
+                p2.set_mesh_table(s2["meshes"])
+                p2.set_instances(s2["pos"], s2["rot"], s2["scale"], s2["mesh_id"])
+                o2 = [DeviceOutputs(torch, s2["n"], device) for _ in range(nf)]
+                kw2 = [o.kwargs() for o in o2]
+                c2 = [0]
 
-            def step2():
-                p2.run_device(f2, async_=True, **kw2)
+                def step2():
+                    k = c2[0]
+                    c2[0] = (k + 1) % nf
+                    p2.run_device(f2, async_=True, **kw2[k])
 
-            dt2 = time_steps(torch, dist, step2, 100, 10, False)
-            kt2 = kernel_event_time(torch, step2, 100, 5)
-            p2.wait()
-            v2 = int(o2.scalars[0].item()) / s2["n"]
-            b2 = s2["n"] * algorithmic_bytes_per_instance(v2)
-            extra[label] = {
-                "instances": s2["n"], "instances_per_s": s2["n"] * 100 / dt2, "ms_per_step": dt2 / 100 * 1e3,
-                "emitted_fraction": v2, "kernel_ms_mean": kt2["mean"], "kernel_ms_min": kt2["min"],
-                "achieved_GBps": b2 / (kt2["mean"] * 1e-3) / 1e9, "frac": b2 / (kt2["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            }
-            p2.close()
-            del o2
+                torch.cuda.synchronize()
+                dt2 = time_steps(torch, dist, step2, 100, 10, False)
+                p2.wait()
+                v2 = int(o2[0].scalars[0].item()) / s2["n"]
+                b2 = s2["n"] * algorithmic_bytes_per_instance(v2)
+                key = "serialized" if nf == 1 else f"frames_in_flight_{nf}"
+                row["emitted_fraction"] = v2
+                row[key] = {"instances_per_s": s2["n"] * 100 / dt2, "ms_per_step": dt2 / 100 * 1e3,
+                            "algorithmic_GBps": b2 / (dt2 / 100) / 1e9, "frac_of_8000": b2 / (dt2 / 100) / 1e9 / HBM_PEAK_GBS}
+                p2.close()
+                del o2
+            extra[label] = row
         result["extra"] = extra
 
     if distributed and not args.no_extra:

@@ -56,6 +56,7 @@ extern "C" {
 /* Largest LOD chain the scene loader can produce: LOD0 + 5 simplified levels
  * (src/renderer/systems/scene_loader.rs:740-753). */
 #define MIP_MAX_LODS 6u
+#define MIP_MAX_FRAMES_IN_FLIGHT 8u
 
 typedef struct MipContext MipContext; /* opaque; Send + Sync like VmaAllocator */
 
@@ -65,8 +66,14 @@ typedef struct MipConfig {
   uint32_t max_instances; /* capacity; the reference's is 4096 (generate_work.comp:25-27) */
   uint32_t max_meshes;    /* capacity of the mesh table */
   uint32_t flags;         /* MIP_CFG_* */
-  uint32_t reserved;
-  void* stream; /* hipStream_t to enqueue on, or NULL for a stream owned by the context */
+  /* Frames the caller keeps in flight (0 or 1 = one): each gets its own stream and its own
+   * cross-tile prefix state inside the context, and consecutive mip_run calls rotate over
+   * them, so frame k+1 may start on the device while frame k drains — what the reference's
+   * per-swapchain-image buffers (DoubleBuffered<..>, src/renderer.rs:1225-1249) allow. The
+   * caller must give `frames_in_flight` consecutive async runs distinct output buffers.
+   * Needs stream == NULL when > 1. */
+  uint32_t frames_in_flight;
+  void* stream; /* hipStream_t to enqueue on, or NULL for streams owned by the context */
 } MipConfig;
 
 /* One entry per distinct mesh. Stands in for GltfMesh.aabb (src/renderer.rs:125),

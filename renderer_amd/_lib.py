@@ -44,7 +44,7 @@ class MipConfig(C.Structure):
         ("max_instances", C.c_uint32),
         ("max_meshes", C.c_uint32),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("frames_in_flight", C.c_uint32),
         ("stream", C.c_void_p),
     ]
 

@@ -26,8 +26,19 @@ struct MipContext {
   uint32_t max_instances = 0, max_meshes = 0, cfg_flags = 0;
   uint32_t n = 0, m = 0;
   bool have_instances = false, have_meshes = false;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
+  // One slot per frame in flight: its own stream and its own cross-tile prefix state, so that
+  // consecutive frames may overlap on the device (MipConfig.frames_in_flight).
+  struct FrameSlot {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    unsigned long long* d_status = nullptr;  // level-0 granules, accumulators, group starts
+    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs)
+    uint32_t epoch = 0;
+    bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
+  };
+  std::vector<FrameSlot> slots;
+  uint32_t next_slot = 0;
+  hipStream_t stream = nullptr;  // = slots[0].stream: uploads, merges, timing
   // resident inputs
   float* d_pos = nullptr;
   float4* d_rot = nullptr;
@@ -36,7 +47,6 @@ struct MipContext {
   mip::MeshEntry* d_meshes = nullptr;
   int32_t* d_vertex_offset = nullptr;
   // look-back state
-  unsigned long long* d_status = nullptr;  // level-0 entries, then 2 x groups_cap accumulators
   size_t status_bytes = 0;
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t epoch = 0;
@@ -44,7 +54,6 @@ struct MipContext {
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU  // instance count changed: clear the prefix state before the next launch
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
-  uint32_t* d_scalars = nullptr;  // [0] draw_count, [1] index_total, [2..3] merge out
   // staging for MIP_OUT_HOST
   float4* s_model = nullptr;
   uint32_t* s_bitmap = nullptr;
@@ -87,6 +96,11 @@ int32_t bind_device(MipContext* ctx) {
   return MIP_OK;
 }
 
+int32_t sync_all(MipContext* ctx) {
+  for (auto& sl : ctx->slots) MIP_HIP(ctx, hipStreamSynchronize(sl.stream));
+  return MIP_OK;
+}
+
 int32_t ensure_staging(MipContext* ctx, const MipOutputs* out) {
   const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
   if (out->model && !ctx->s_model) MIP_HIP(ctx, hipMalloc(&ctx->s_model, cap * 64));
@@ -113,15 +127,18 @@ int32_t check_device_error(MipContext* ctx) {
 void free_all(MipContext* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& sl : ctx->slots)
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   (void)hipFree(ctx->d_pos);
   (void)hipFree(ctx->d_rot);
   (void)hipFree(ctx->d_scale);
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
   (void)hipFree(ctx->d_vertex_offset);
-  (void)hipFree(ctx->d_status);
-  (void)hipFree(ctx->d_scalars);
+  for (auto& sl : ctx->slots) {
+    (void)hipFree(sl.d_status);
+    (void)hipFree(sl.d_scalars);
+  }
   (void)hipFree(ctx->s_model);
   (void)hipFree(ctx->s_bitmap);
   (void)hipFree(ctx->s_cmds);
@@ -129,7 +146,8 @@ void free_all(MipContext* ctx) {
   if (ctx->h_error) (void)hipHostFree(ctx->h_error);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (auto& sl : ctx->slots)
+    if (sl.own_stream && sl.stream) (void)hipStreamDestroy(sl.stream);
   delete ctx;
 }
 
@@ -143,6 +161,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
   if (out) *out = nullptr;
   if (!cfg || !out || cfg->struct_size != sizeof(MipConfig)) return MIP_ERR_INVALID_ARGUMENT;
   if (cfg->max_instances > 0x3fffffffu) return MIP_ERR_INVALID_ARGUMENT;
+  if (cfg->frames_in_flight > MIP_MAX_FRAMES_IN_FLIGHT) return MIP_ERR_INVALID_ARGUMENT;
+  if (cfg->frames_in_flight > 1 && cfg->stream) return MIP_ERR_INVALID_ARGUMENT;  // one caller stream cannot overlap frames
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MIP_ERR_NO_DEVICE;
   if (cfg->device_ordinal < 0 || cfg->device_ordinal >= count) return MIP_ERR_NO_DEVICE;
@@ -160,12 +180,17 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
 
   int32_t rc = [&]() -> int32_t {
     MIP_HIP(ctx, hipSetDevice(ctx->device));
-    if (cfg->stream) {
-      ctx->stream = (hipStream_t)cfg->stream;
-    } else {
-      MIP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-      ctx->own_stream = true;
+    const uint32_t frames = cfg->frames_in_flight ? cfg->frames_in_flight : 1u;
+    ctx->slots.resize(frames);
+    for (auto& sl : ctx->slots) {
+      if (cfg->stream) {
+        sl.stream = (hipStream_t)cfg->stream;  // frames == 1 (checked above)
+      } else {
+        MIP_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        sl.own_stream = true;
+      }
     }
+    ctx->stream = ctx->slots[0].stream;
     const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
     const size_t mcap = ctx->max_meshes ? ctx->max_meshes : 1;
     MIP_HIP(ctx, hipMalloc(&ctx->d_pos, cap * 12));
@@ -180,10 +205,12 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     ctx->acc1_offset_words = (uint32_t)((tiles_cap + 31) / 32 * 32);  // keep the accumulators 256-B aligned
     ctx->start1_offset_words = ctx->acc1_offset_words + ctx->groups_cap * 2 * mip::kAccStrideWords;
     ctx->status_bytes = ((size_t)ctx->start1_offset_words + (size_t)ctx->groups_cap * 2) * 8;
-    MIP_HIP(ctx, hipMalloc(&ctx->d_status, ctx->status_bytes));
-    MIP_HIP(ctx, hipMemset(ctx->d_status, 0, ctx->status_bytes));  // epoch 0 is never used
-    MIP_HIP(ctx, hipMalloc(&ctx->d_scalars, 64));
-    MIP_HIP(ctx, hipMemset(ctx->d_scalars, 0, 64));
+    for (auto& sl : ctx->slots) {
+      MIP_HIP(ctx, hipMalloc(&sl.d_status, ctx->status_bytes));
+      MIP_HIP(ctx, hipMemset(sl.d_status, 0, ctx->status_bytes));  // epoch 0 is never used
+      MIP_HIP(ctx, hipMalloc(&sl.d_scalars, 64));
+      MIP_HIP(ctx, hipMemset(sl.d_scalars, 0, 64));
+    }
     MIP_HIP(ctx, hipHostMalloc(&ctx->h_error, 64, hipHostMallocMapped));
     std::memset(ctx->h_error, 0, 64);
     MIP_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_error, ctx->h_error, 0));
@@ -227,7 +254,7 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
     voff[k] = s.vertex_offset;
   }
   if (int32_t rc = bind_device(ctx)) return rc;
-  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (int32_t rc = sync_all(ctx)) return rc;
   if (m) {
     MIP_HIP(ctx, hipMemcpy(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice));
     MIP_HIP(ctx, hipMemcpy(ctx->d_vertex_offset, voff.data(), m * 4, hipMemcpyHostToDevice));
@@ -243,14 +270,15 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
     return fail(ctx, MIP_ERR_CAPACITY, "%u instances > max_instances %u", n, ctx->max_instances);
   if (n && (!pos || !rot || !scale || !mesh_id)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL instance column");
   if (int32_t rc = bind_device(ctx)) return rc;
-  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (int32_t rc = sync_all(ctx)) return rc;
   if (n) {
     MIP_HIP(ctx, hipMemcpy(ctx->d_pos, pos, (size_t)n * 12, kind));
     MIP_HIP(ctx, hipMemcpy(ctx->d_rot, rot, (size_t)n * 16, kind));
     MIP_HIP(ctx, hipMemcpy(ctx->d_scale, scale, (size_t)n * 4, kind));
     MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind));
   }
-  if (n != ctx->n) ctx->status_dirty = true;  // tile/group geometry changes with n
+  if (n != ctx->n)
+    for (auto& sl : ctx->slots) sl.status_dirty = true;  // tile/group geometry changes with n
   ctx->n = n;
   ctx->have_instances = true;
   return MIP_OK;
@@ -288,6 +316,12 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
   if (int32_t rc = bind_device(ctx)) return rc;
 
+  // Frames rotate over the slots; a slot's stream orders a frame after the frame that last
+  // used the same prefix state.
+  MipContext::FrameSlot& sl = ctx->slots[ctx->next_slot];
+  ctx->next_slot = (ctx->next_slot + 1) % (uint32_t)ctx->slots.size();
+  hipStream_t stream = sl.stream;
+
   const uint32_t n = ctx->n;
   const uint32_t words = (n + 31u) / 32u;
   if (!device_out)
@@ -299,12 +333,12 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.model = out->model ? (device_out ? (float4*)out->model : ctx->s_model) : nullptr;
   a.bitmap = out->visible_bitmap ? (device_out ? out->visible_bitmap : ctx->s_bitmap) : nullptr;
   a.cmds = out->draw_cmds ? (device_out ? (uint32_t*)out->draw_cmds : ctx->s_cmds) : nullptr;
-  a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : ctx->d_scalars + 0) : nullptr;
-  a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : ctx->d_scalars + 1) : nullptr;
+  a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : sl.d_scalars + 0) : nullptr;
+  a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : sl.d_scalars + 1) : nullptr;
   a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
-  a.status0 = ctx->d_status;
-  a.acc1 = ctx->d_status + ctx->acc1_offset_words;
-  a.start1 = ctx->d_status + ctx->start1_offset_words;
+  a.status0 = sl.d_status;
+  a.acc1 = sl.d_status + ctx->acc1_offset_words;
+  a.start1 = sl.d_status + ctx->start1_offset_words;
   a.groups_cap = ctx->groups_cap;
   a.error_flag = ctx->d_error;
   a.n = n;
@@ -324,44 +358,44 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.n_tiles = tiles_for(n);
   a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
   if (a.cmds && n) {
-    if (ctx->status_dirty || ctx->epoch >= mip::kMaxEpoch) {
-      MIP_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, ctx->status_bytes, ctx->stream));
-      ctx->status_dirty = false;
-      ctx->epoch = 0;
+    if (sl.status_dirty || sl.epoch >= mip::kMaxEpoch) {
+      MIP_HIP(ctx, hipMemsetAsync(sl.d_status, 0, ctx->status_bytes, stream));
+      sl.status_dirty = false;
+      sl.epoch = 0;
     }
-    a.epoch = ++ctx->epoch;
+    a.epoch = ++sl.epoch;
   }
 
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0;
   if (n == 0) {
-    if (a.draw_count) MIP_HIP(ctx, hipMemsetAsync(a.draw_count, 0, 4, ctx->stream));
-    if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, ctx->stream));
+    if (a.draw_count) MIP_HIP(ctx, hipMemsetAsync(a.draw_count, 0, 4, stream));
+    if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, stream));
   } else {
-    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, ctx->stream, a);
+    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, stream, a);
     MIP_HIP(ctx, hipGetLastError());
-    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, stream));
   }
 
   if (!device_out) {
     if (n) {
-      if (out->model) MIP_HIP(ctx, hipMemcpyAsync(out->model, ctx->s_model, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->visible_bitmap) MIP_HIP(ctx, hipMemcpyAsync(out->visible_bitmap, ctx->s_bitmap, (size_t)words * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (out->world_aabb) MIP_HIP(ctx, hipMemcpyAsync(out->world_aabb, ctx->s_aabb, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+      if (out->model) MIP_HIP(ctx, hipMemcpyAsync(out->model, ctx->s_model, (size_t)n * 64, hipMemcpyDeviceToHost, stream));
+      if (out->visible_bitmap) MIP_HIP(ctx, hipMemcpyAsync(out->visible_bitmap, ctx->s_bitmap, (size_t)words * 4, hipMemcpyDeviceToHost, stream));
+      if (out->world_aabb) MIP_HIP(ctx, hipMemcpyAsync(out->world_aabb, ctx->s_aabb, (size_t)n * 24, hipMemcpyDeviceToHost, stream));
     }
     uint32_t scalars[2] = {0, 0};
     if (out->draw_cmds) {
-      MIP_HIP(ctx, hipMemcpyAsync(scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
-      MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MIP_HIP(ctx, hipMemcpyAsync(scalars, sl.d_scalars, 8, hipMemcpyDeviceToHost, stream));
+      MIP_HIP(ctx, hipStreamSynchronize(stream));
       if (scalars[0] > n) return fail(ctx, MIP_ERR_DEVICE, "draw_count %u > n %u", scalars[0], n);
       if (scalars[0])
-        MIP_HIP(ctx, hipMemcpyAsync(out->draw_cmds, ctx->s_cmds, (size_t)scalars[0] * 20, hipMemcpyDeviceToHost, ctx->stream));
+        MIP_HIP(ctx, hipMemcpyAsync(out->draw_cmds, ctx->s_cmds, (size_t)scalars[0] * 20, hipMemcpyDeviceToHost, stream));
       *out->draw_count = scalars[0];
       if (out->draw_index_total) *out->draw_index_total = scalars[1];
     }
-    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIP_HIP(ctx, hipStreamSynchronize(stream));
   } else if (!async) {
-    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MIP_HIP(ctx, hipStreamSynchronize(stream));
   }
 
   if (async) {
@@ -381,7 +415,7 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
 int32_t mip_wait(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;
-  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (int32_t rc = sync_all(ctx)) return rc;
   ctx->pending_async = false;
   return check_device_error(ctx);
 }

@@ -44,7 +44,7 @@ def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0):
 class InstancePipeline:
     """One context on one GPU (one per rank)."""
 
-    def __init__(self, max_instances, max_meshes, device=0, timing=False, stream=None):
+    def __init__(self, max_instances, max_meshes, device=0, timing=False, stream=None, frames_in_flight=1):
         self._lib = _lib.load_library()
         self._ctx = C.c_void_p()
         cfg = MipConfig()
@@ -53,6 +53,7 @@ class InstancePipeline:
         cfg.max_instances = int(max_instances)
         cfg.max_meshes = int(max_meshes)
         cfg.flags = _lib.MIP_CFG_TIMING if timing else 0
+        cfg.frames_in_flight = int(frames_in_flight)
         cfg.stream = stream
         rc = self._lib.mip_create(C.byref(cfg), C.byref(self._ctx))
         if rc != 0:

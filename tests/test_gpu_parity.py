@@ -337,3 +337,41 @@ print("RECOVERED", r["draw_count"])
     assert code_line and code_line[0].split()[1] == "-7", out.stdout  # MIP_ERR_TIMEOUT
     assert float(code_line[0].split()[2]) < 10.0
     assert any(l.startswith("RECOVERED") and int(l.split()[1]) > 0 for l in lines), out.stdout
+
+
+def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):
+    """Three frames in flight with different cameras and their own output buffers: all correct."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=300_000)
+    dev = torch.device("cuda", 0)
+    cams = [np.array(c, np.float32) for c in ((0, 1, 2), (5, 1, 2), (0, 1, 30))]
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=3) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        bufs = []
+        for _ in range(3):
+            cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            bitmap = torch.zeros((s["n"] + 31) // 32, dtype=torch.int32, device=dev)
+            bufs.append((cmds, scal, bitmap))
+        torch.cuda.synchronize()
+        for rep in range(4):  # 12 async launches rotating over the 3 slots
+            for k in range(3):
+                cmds, scal, bitmap = bufs[k]
+                p.run_device(make_frame(s["planes"], cams[k]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                             draw_index_total=scal.data_ptr() + 4, visible_bitmap=bitmap.data_ptr(), async_=True)
+        p.wait()
+        for k in range(3):
+            cmds, scal, bitmap = bufs[k]
+            want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], cams[k],
+                                  threads=8, want=("draw_cmds", "visible_bitmap"))
+            count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+            assert count == want["draw_count"] and total == want["draw_index_total"]
+            got = cmds[:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+            assert got.tobytes() == want["draw_cmds"].tobytes()
+            assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
+    with pytest.raises(ra.MipError):
+        ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=99)
