@@ -176,7 +176,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world and distributed:
+    if os.environ.get("MIP_BENCH_FORCE_DIST") == "1":  # rehearsal of the N>1 code paths with one rank
+        distributed = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the instance pipeline has no CPU path")
@@ -215,13 +221,14 @@ def main():
         exchange = DrawListExchange(pipe, n_local, world, rank, device)
 
     if exchange is None:
-        kws = [o.kwargs() for o in out_sets]
+        prepared = [pipe.prepare_outputs(**o.kwargs()) for o in out_sets]  # one foreign call per frame
+        fref = pipe.frame_ref(frame)
         counter = [0]
 
         def step():
             k = counter[0]
             counter[0] = (k + 1) % frames
-            pipe.run_device(frame, async_=True, **kws[k])
+            pipe.run_prepared(fref, prepared[k])
     else:
         def step():
             exchange.step(frame, outs)
@@ -280,10 +287,11 @@ def main():
                                                    device=local_rank, stream=stream)
             serial.set_mesh_table(s["meshes"])
             serial.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-        kw = outs.kwargs()
+        serial_out = serial.prepare_outputs(**outs.kwargs())
+        serial_frame = serial.frame_ref(frame)
 
         def kernel_only():
-            serial.run_device(frame, async_=True, **kw)
+            serial.run_prepared(serial_frame, serial_out)
 
         kt = kernel_event_time(torch, kernel_only, max(args.steps, 50), args.warmup)
         serial.wait()
@@ -328,13 +336,14 @@ def main():
                 p2.set_mesh_table(s2["meshes"])
                 p2.set_instances(s2["pos"], s2["rot"], s2["scale"], s2["mesh_id"])
                 o2 = [DeviceOutputs(torch, s2["n"], device) for _ in range(nf)]
-                kw2 = [o.kwargs() for o in o2]
+                kw2 = [p2.prepare_outputs(**o.kwargs()) for o in o2]
+                f2r = p2.frame_ref(f2)
                 c2 = [0]
 
                 def step2():
                     k = c2[0]
                     c2[0] = (k + 1) % nf
-                    p2.run_device(f2, async_=True, **kw2[k])
+                    p2.run_prepared(f2r, kw2[k])
 
                 torch.cuda.synchronize()
                 dt2 = time_steps(torch, dist, step2, 100, 10, False)

@@ -113,7 +113,7 @@ def load_library():
     lib.mip_set_instances.restype = C.c_int32
     lib.mip_set_instances_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.mip_set_instances_device.restype = C.c_int32
-    lib.mip_run.argtypes = [vp, C.POINTER(MipFrame), C.POINTER(MipOutputs)]
+    lib.mip_run.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.mip_run.restype = C.c_int32
     lib.mip_wait.argtypes = [vp]
     lib.mip_wait.restype = C.c_int32

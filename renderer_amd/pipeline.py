@@ -153,6 +153,32 @@ class InstancePipeline:
         out.world_aabb = world_aabb or None
         self._check(self._lib.mip_run(self._ctx, C.byref(frame), C.byref(out)))
 
+    def prepare_outputs(self, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0, draw_index_total=0,
+                        world_aabb=0, async_=True):
+        """A reusable MipOutputs (device pointers) for run_prepared: keeps the per-frame host cost
+        to one foreign call."""
+        out = MipOutputs()
+        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
+        out.model = model or None
+        out.visible_bitmap = visible_bitmap or None
+        out.draw_cmds = draw_cmds or None
+        out.draw_count = draw_count or None
+        out.draw_index_total = draw_index_total or None
+        out.world_aabb = world_aabb or None
+        out._as_parameter_ = C.c_void_p(C.addressof(out))  # lets ctypes pass the struct by address
+        return out
+
+    @staticmethod
+    def frame_ref(frame):
+        """A MipFrame prepared for run_prepared (passed by address)."""
+        frame._as_parameter_ = C.c_void_p(C.addressof(frame))
+        return frame
+
+    def run_prepared(self, frame, outputs):
+        rc = self._lib.mip_run(self._ctx, frame, outputs)
+        if rc != 0:
+            self._check(rc)
+
     def wait(self):
         self._check(self._lib.mip_wait(self._ctx))
 

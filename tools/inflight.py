@@ -30,17 +30,19 @@ for F in (1, 2, 3, 4):
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
         kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
                   draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
-        ctxs.append((p, kw, (model, bitmap, cmds, scal), st))
+        prepared = p.prepare_outputs(**kw)
+        ctxs.append((p, prepared, (model, bitmap, cmds, scal), st))
     frame = make_frame(s["planes"], s["cam_pos"])
+    fref = renderer_amd.InstancePipeline.frame_ref(frame)
     for k in range(20):
         p, kw, _, _ = ctxs[k % F]
-        p.run_device(frame, async_=True, **kw)
+        p.run_prepared(fref, kw)
     torch.cuda.synchronize()
     K = 400
     t0 = time.perf_counter()
     for k in range(K):
         p, kw, _, _ = ctxs[k % F]
-        p.run_device(frame, async_=True, **kw)
+        p.run_prepared(fref, kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
     print(f"config {config} frames in flight {F}: {dt*1e6:.2f} us/step  {n/dt/1e9:.2f} G inst/s", flush=True)
