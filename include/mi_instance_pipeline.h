@@ -107,6 +107,9 @@ typedef struct MipFrame {
   float cam_pos[3];           /* Camera.position, for pick_lod */
   uint32_t first_instance_base; /* added to firstInstance: draw_index of instance 0 of this shard */
   uint32_t first_index_base;    /* added to firstIndex (wrapping u32) */
+  /* CameraMatrices.pv = projection * view, column-major (generate_work.comp:29-34). Only read
+   * when MipOutputs.culled_index_buffer is set (per-triangle culling). */
+  float pv[16];
 } MipFrame;
 
 typedef struct MipOutputs {
@@ -129,6 +132,16 @@ typedef struct MipOutputs {
   void* world_aabb;
   uint32_t flags; /* MIP_OUT_* */
   uint32_t reserved;
+  /* Optional (needs MIP_OUT_DEVICE, mip_set_geometry, model and draw_cmds): the culled index
+   * stream `uvec3 out_index_buffer[]` (CulledIndexBuffer, generate_work.comp:40-42). When set,
+   * every emitted command's triangles go through the per-triangle back-face + x/y frustum test
+   * of generate_work.comp:68-200; survivors are appended, in mesh order, at
+   * culled_index_buffer[firstIndex ...]; indexCount becomes 3 x survivors and commands without
+   * survivors are dropped by the compaction that follows (compact_draw_stream.comp runs after
+   * generate_work). firstIndex keeps the reference's layout: the running sum of the full
+   * index_len of the earlier commands. */
+  void* culled_index_buffer;
+  uint64_t culled_index_capacity; /* in indices (u32); a command that would not fit raises MIP_ERR_CAPACITY */
 } MipOutputs;
 
 typedef struct MipTimings {
@@ -176,6 +189,13 @@ int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* ro
  * not validated — the caller guarantees id < m). */
 int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw,
                                  const void* scale, const void* mesh_id, uint32_t n);
+
+/* Upload the consolidated geometry the per-triangle stage reads (ConsolidatedMeshBuffers'
+ * position_buffer and index_buffer, consolidate_mesh_buffers.rs): packed vec3 positions and
+ * u32 indices; MipMesh.vertex_offset / index_offset[] index into them. Host pointers; copied. */
+int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_vertices,
+                         const uint32_t* indices, uint32_t n_indices);
+
 
 /* One frame: model matrices, world AABBs, visibility, compacted draw commands.
  * Call from one thread at a time per context. Synchronous on return unless

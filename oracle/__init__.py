@@ -16,4 +16,6 @@ from .oracle import (  # noqa: F401
     project_camera,
     compact_draw_stream,
     merge_draw_lists,
+    camera_pv,
+    cull_all_triangles,
 )

@@ -192,10 +192,10 @@ uint32_t orc_pick_lod(uint32_t n_lods, const float cam_pos[3], const float mesh_
   return (distance_from_camera > 10.0f && n_lods > 1) ? 1u : 0u;
 }
 
-/* src/ecs.rs:66-91 (see header: input producer, not bit-pinned) */
-void orc_project_camera(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect,
-                        float fovy_degrees, float near_z, float far_z, float planes[24]) {
-  float proj[16], view[16], rot[16], pv[16];
+/* src/ecs.rs:66-82 (see header: input producer, not bit-pinned) */
+void orc_camera_pv(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect, float fovy_degrees,
+                   float near_z, float far_z, float pv[16]) {
+  float proj[16], view[16], rot[16];
   memset(proj, 0, sizeof proj);
   const float fovy = fovy_degrees * (3.14159265358979323846f / 180.0f);
   const float tan_half_fovy = tanf(fovy / 2.0f);
@@ -227,6 +227,13 @@ void orc_project_camera(const float cam_pos[3], const float cam_rot_ijkw[4], flo
   view[14] = -dot3(z, cam_pos);
   view[15] = 1.0f;
   orc_mat4_mul(proj, view, pv); /* m = camera.projection * camera.view */
+}
+
+/* src/ecs.rs:82-90 */
+void orc_project_camera(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect,
+                        float fovy_degrees, float near_z, float far_z, float planes[24]) {
+  float pv[16];
+  orc_camera_pv(cam_pos, cam_rot_ijkw, aspect, fovy_degrees, near_z, far_z, pv);
   /* -(row3 +/- row k), k = 0,1,2: left, right, bottom, top, near, far (src/ecs.rs:83-90) */
   for (int k = 0; k < 3; ++k)
     for (int c = 0; c < 4; ++c) {
@@ -464,4 +471,108 @@ uint32_t orc_merge_draw_lists(uint32_t n_shards, const OrcDrawCmd* const* lists,
   }
   if (out_index_total) *out_index_total = index_base;
   return at;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* row f-1: per-triangle cull + index-stream append (generate_work.comp:68-200)          */
+/* ------------------------------------------------------------------------------------ */
+
+/* GLSL mat4 * vec4, fixed here as the column combination left to right, no FMA. */
+static void glsl_mat4_mul_vec4(const float m[16], const float v[4], float out[4]) {
+  for (int r = 0; r < 4; ++r) out[r] = ((m[0 * 4 + r] * v[0] + m[1 * 4 + r] * v[1]) + m[2 * 4 + r] * v[2]) + m[3 * 4 + r] * v[3];
+}
+
+uint32_t orc_cull_triangles(const OrcDrawCmd* cmd, uint32_t src_index_offset, const float model[16],
+                            const float pv[16], const float* vertex_buffer, const uint32_t* index_buffer,
+                            uint32_t* out_index_buffer) {
+  const uint32_t n_tris = cmd->indexCount / 3;             /* `indexCount / 3`, :77 */
+  uint32_t survivors = 0;
+  for (uint32_t t = 0; t < n_tris; ++t) {
+    const uint32_t* ix = &index_buffer[(size_t)(src_index_offset / 3 + t) * 3]; /* index_buffer[indexOffset / 3 + id], :78 */
+    float clip[3][4];
+    for (int k = 0; k < 3; ++k) {
+      const float* p = &vertex_buffer[(size_t)((int64_t)cmd->vertexOffset + (int64_t)ix[k]) * 3]; /* :121,:135 */
+      const float vh[4] = {p[0], p[1], p[2], 1.0f};
+      float world[4];
+      glsl_mat4_mul_vec4(model, vh, world);                /* model_mat * vec4(v, 1.0), :138-140 */
+      glsl_mat4_mul_vec4(pv, world, clip[k]);              /* pv * (...) */
+    }
+    /* determinant(mat3(v0.xyw, v1.xyw, v2.xyw)) > 0: columns are the xyw of the three vertices, :143 */
+    const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
+    const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][3];
+    const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][3];
+    const float det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) + a20 * (a01 * a12 - a11 * a02);
+    int cull = det > 0.0f;
+    float ndc[3][2];
+    for (int k = 0; k < 3; ++k) {
+      ndc[k][0] = clip[k][0] / clip[k][3];                 /* vertex.xyz / vertex.w, :145-147 (z unused below) */
+      ndc[k][1] = clip[k][1] / clip[k][3];
+    }
+    if (!cull)
+      cull = (ndc[0][0] < -1.0f && ndc[1][0] < -1.0f && ndc[2][0] < -1.0f) ||
+             (ndc[0][0] > 1.0f && ndc[1][0] > 1.0f && ndc[2][0] > 1.0f) ||
+             (ndc[0][1] < -1.0f && ndc[1][1] < -1.0f && ndc[2][1] < -1.0f) ||
+             (ndc[0][1] > 1.0f && ndc[1][1] > 1.0f && ndc[2][1] > 1.0f); /* :149-155 */
+    /* the degenerate-triangle test is disabled in the reference (`cull = false`, :165) */
+    if (!cull) {
+      uint32_t* dst = &out_index_buffer[((size_t)cmd->firstIndex / 3 + survivors) * 3]; /* :181-190 */
+      dst[0] = ix[0]; dst[1] = ix[1]; dst[2] = ix[2];
+      ++survivors;
+    }
+  }
+  return survivors * 3;
+}
+
+void orc_src_index_offsets(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id, const uint8_t* coarse_culled,
+                           const OrcMesh* meshes, const float cam_pos[3], uint32_t* out) {
+  uint32_t at = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (coarse_culled[i]) continue;
+    const OrcMesh* mesh = &meshes[mesh_id[i]];
+    const uint32_t lod = orc_pick_lod(mesh->n_lods, cam_pos, &pos_xyz[(size_t)i * 3]);
+    if (mesh->index_len[lod] > 0) out[at++] = mesh->index_offset[lod];
+  }
+}
+
+typedef struct TriJob {
+  OrcDrawCmd* cmds;
+  uint32_t begin, end;
+  const uint32_t* src;
+  const float* model;
+  uint32_t base;
+  const float* pv;
+  const float* vb;
+  const uint32_t* ib;
+  uint32_t* out;
+} TriJob;
+
+static void* tri_job(void* arg) {
+  TriJob* j = (TriJob*)arg;
+  for (uint32_t k = j->begin; k < j->end; ++k) {
+    OrcDrawCmd* c = &j->cmds[k];
+    const float* m = &j->model[(size_t)(c->firstInstance - j->base) * 16]; /* model[gltfIndex] */
+    c->indexCount = orc_cull_triangles(c, j->src[k], m, j->pv, j->vb, j->ib, j->out);
+  }
+  return NULL;
+}
+
+uint32_t orc_cull_all_triangles(OrcDrawCmd* cmds, uint32_t count, const uint32_t* src_index_offset,
+                                const float* model, uint32_t first_instance_base, const float pv[16],
+                                const float* vertex_buffer, const uint32_t* index_buffer,
+                                uint32_t* out_index_buffer, uint32_t threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  TriJob jobs[256];
+  pthread_t tids[256];
+  const uint32_t chunk = (count + threads - 1) / threads;
+  for (uint32_t t = 0; t < threads; ++t) {
+    const uint64_t b = (uint64_t)t * chunk, e = b + chunk;
+    jobs[t] = (TriJob){cmds, (uint32_t)(b < count ? b : count), (uint32_t)(e < count ? e : count), src_index_offset,
+                       model, first_instance_base, pv, vertex_buffer, index_buffer, out_index_buffer};
+  }
+  for (uint32_t t = 1; t < threads; ++t) pthread_create(&tids[t], NULL, tri_job, &jobs[t]);
+  tri_job(&jobs[0]);
+  for (uint32_t t = 1; t < threads; ++t) pthread_join(tids[t], NULL);
+  /* compact_draw_stream.comp runs after generate_work: commands whose triangles all died vanish */
+  return orc_compact_draw_stream(cmds, count, cmds);
 }

@@ -125,6 +125,44 @@ uint32_t orc_merge_draw_lists(uint32_t n_shards, const OrcDrawCmd* const* lists,
                               const uint32_t* counts, const uint32_t* index_totals,
                               OrcDrawCmd* out, uint32_t* out_index_total);
 
+/* ---- row f-1: per-triangle cull + index-stream append ------------------------------------
+ * src/shaders/generate_work.comp:68-200 for ONE draw command (one visible instance):
+ * for every triangle of the picked LOD, in triangle order: fetch the index triple and the
+ * three positions, clip = pv * (model * vec4(v, 1)), cull when the triangle is back-facing
+ * (determinant of the xyw columns > 0) or all three vertices are beyond the same x or y
+ * NDC bound, append the surviving index triples at out_index_buffer[firstIndex/3 + k].
+ * Returns 3 x survivors (the command's final indexCount).
+ *
+ * PARITY UNPINNED, doubly: the reference evaluates this in GLSL on a Vulkan driver, which
+ * fixes neither the summation order of mat*vec nor FMA contraction nor the determinant's
+ * expansion. This restatement fixes them (column combination left to right, no FMA,
+ * cofactor expansion along the x components of the three vertices, true division for the perspective divide);
+ * where workgroups race in the reference (the order of surviving triangles across
+ * workgroups, generate_work.comp:176-186) it emits the stable order.
+ *   index_buffer / vertex_buffer : the consolidated buffers (u32 indices; packed vec3)
+ *   src_index_offset             : push constant indexOffset (start of the LOD's indices)
+ */
+uint32_t orc_cull_triangles(const OrcDrawCmd* cmd, uint32_t src_index_offset, const float model[16],
+                            const float pv[16], const float* vertex_buffer, const uint32_t* index_buffer,
+                            uint32_t* out_index_buffer);
+
+/* The per-frame sequence with per-triangle culling: instance path -> per command triangle
+ * cull (rewrites indexCount) -> compaction on indexCount > 0. `cmds`/`count` are the output of
+ * orc_run (indexCount = index_len); src_index_offset[k] belongs to cmds[k]. Returns the new count. */
+uint32_t orc_cull_all_triangles(OrcDrawCmd* cmds, uint32_t count, const uint32_t* src_index_offset,
+                                const float* model, uint32_t first_instance_base, const float pv[16],
+                                const float* vertex_buffer, const uint32_t* index_buffer,
+                                uint32_t* out_index_buffer, uint32_t threads);
+
+/* index_offset of the LOD each emitted command draws from (what cull_pass puts in the push
+ * constants, cull_pipeline.rs:545-553), in command order. */
+void orc_src_index_offsets(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id, const uint8_t* coarse_culled,
+                           const OrcMesh* meshes, const float cam_pos[3], uint32_t* out);
+
+/* CameraMatrices.pv = projection * view for orc_project_camera's camera (column-major). */
+void orc_camera_pv(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect, float fovy_degrees,
+                   float near_z, float far_z, float pv[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ def lib():
         _lib.orc_pick_lod.restype = C.c_uint32
         _lib.orc_compact_draw_stream.restype = C.c_uint32
         _lib.orc_merge_draw_lists.restype = C.c_uint32
+        _lib.orc_cull_all_triangles.restype = C.c_uint32
     return _lib
 
 
@@ -133,6 +134,38 @@ def merge_draw_lists(lists, index_totals):
     n = lib().orc_merge_draw_lists(C.c_uint32(len(lists)), ptrs, _p(counts), _p(totals), _p(out),
                                    C.byref(tot))
     return out[:n], int(tot.value)
+
+
+def camera_pv(cam_pos=(0.0, 1.0, 2.0), cam_rot_ijkw=(0.0, 0.0, 0.0, 1.0), aspect=2.0, fovy_degrees=70.0,
+              near=0.1, far=100.0):
+    pv = np.empty(16, np.float32)
+    lib().orc_camera_pv(_p(_f32(cam_pos)), _p(_f32(cam_rot_ijkw)), C.c_float(aspect), C.c_float(fovy_degrees),
+                        C.c_float(near), C.c_float(far), _p(pv))
+    return pv
+
+
+def cull_all_triangles(res, pos_xyz, mesh_id, meshes, cam_pos, pv, vertices, indices, first_instance_base=0,
+                       out_capacity=None, threads=8):
+    """Row f-1 on top of a `run` result (needs model, coarse_culled, draw_cmds). Returns
+    (final commands, culled index stream as u32 array of length out_capacity)."""
+    pos_xyz = _f32(pos_xyz).reshape(-1, 3)
+    n = pos_xyz.shape[0]
+    mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32)
+    meshes = np.ascontiguousarray(meshes, dtype=ORC_MESH_DTYPE)
+    cmds = np.ascontiguousarray(res["draw_cmds"], dtype=DRAW_CMD_DTYPE).copy()
+    count = len(cmds)
+    src = np.zeros(max(count, 1), np.uint32)
+    culled = np.ascontiguousarray(res["coarse_culled"], dtype=np.uint8)
+    lib().orc_src_index_offsets(C.c_uint32(n), _p(pos_xyz), _p(mesh_id), _p(culled), _p(meshes), _p(_f32(cam_pos, (3,))), _p(src))
+    if out_capacity is None:
+        out_capacity = int(res["draw_index_total"]) + 3
+    out = np.full(int(out_capacity), 0xFFFFFFFF, np.uint32)
+    vertices = _f32(vertices).reshape(-1, 3)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    model = _f32(res["model"]).reshape(-1, 16)
+    new_count = lib().orc_cull_all_triangles(_p(cmds), C.c_uint32(count), _p(src), _p(model), C.c_uint32(first_instance_base),
+                                             _p(_f32(pv, (16,))), _p(vertices), _p(indices), _p(out), C.c_uint32(threads))
+    return cmds[:new_count].copy(), out, src[:count].copy()
 
 
 def run(pos_xyz, rot_ijkw, scale, mesh_id, meshes, planes, cam_pos, first_instance_base=0,

@@ -26,7 +26,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_run", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
+    "mip_set_instances_device", "mip_set_geometry", "mip_run", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -55,6 +55,7 @@ class MipFrame(C.Structure):
         ("cam_pos", C.c_float * 3),
         ("first_instance_base", C.c_uint32),
         ("first_index_base", C.c_uint32),
+        ("pv", C.c_float * 16),
     ]
 
 
@@ -68,6 +69,8 @@ class MipOutputs(C.Structure):
         ("world_aabb", C.c_void_p),
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("culled_index_buffer", C.c_void_p),
+        ("culled_index_capacity", C.c_uint64),
     ]
 
 
@@ -100,6 +103,13 @@ def load_library():
             f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C renderer_amd/csrc`. The instance pipeline has no CPU fallback."
         )
+    # torch wheels bundle their own libamdhip64.so.7. Whichever copy of that SONAME is loaded first
+    # serves the whole process, and torch cannot initialise on top of /opt/rocm's copy ("No HIP GPUs
+    # are available"), so in a process that has torch, torch's runtime must come first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_SO)
     vp = C.c_void_p
     lib.mip_abi_version.restype = C.c_uint32
@@ -113,6 +123,8 @@ def load_library():
     lib.mip_set_instances.restype = C.c_int32
     lib.mip_set_instances_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.mip_set_instances_device.restype = C.c_int32
+    lib.mip_set_geometry.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.mip_set_geometry.restype = C.c_int32
     lib.mip_run.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.mip_run.restype = C.c_int32
     lib.mip_wait.argtypes = [vp]

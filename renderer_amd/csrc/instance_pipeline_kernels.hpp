@@ -37,6 +37,7 @@ namespace mip {
 constexpr uint32_t kTile = 256;           // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
+constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
 // len0 = index_len[0]; len1 = index_len[1] if n_lods > 1 else index_len[0]
@@ -48,18 +49,27 @@ struct alignas(16) MeshEntry {
   uint32_t len1;
 };
 
+// Per-mesh draw data, one 16-B gather for the lanes that emit a command.
+struct alignas(16) MeshDraw {
+  int32_t vertex_offset;  // ConsolidatedMeshBuffers.vertex_offsets[mesh]
+  uint32_t src_offset0;   // index_offsets[LOD 0] in the consolidated index buffer
+  uint32_t src_offset1;   // index_offsets[LOD 1] (= LOD 0's when there is only one)
+  uint32_t pad;
+};
+
 struct KernelArgs {
   const float* pos;             // n*3
   const float4* rot;            // n  [i,j,k,w]
   const float* scale;           // n
   const uint32_t* mesh_id;      // n
   const MeshEntry* meshes;      // m
-  const int32_t* vertex_offset; // m
+  const MeshDraw* mesh_draw;    // m
   float4* model;                // n*4 or null
   uint32_t* bitmap;             // ceil(n/32) or null
   uint32_t* cmds;               // n*5 or null
   uint32_t* draw_count;         // with cmds
   uint32_t* index_total;        // optional
+  uint32_t* src_index_offset;   // optional: per emitted command, where its LOD's indices start (row f-1)
   float* world_aabb;            // n*6 or null
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   // stored their matrices: 13.6 KB of LDS per workgroup instead of 18.5 KB, so that more
   // workgroups whose wave 0 is still waiting for its prefix fit beside the running ones.
   uint32_t* const s_cmd = reinterpret_cast<uint32_t*>(&s_mat[64 * 12]);
-  static_assert((kTile - 64) * 12 >= kTile * kCmdWords, "commands must fit the staging area of waves 1-3");
+  static_assert((kTile - 64) * 12 >= kTile * kCmdLdsWords, "commands must fit the staging area of waves 1-3");
   __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   const bool visible = active && !culled;
   const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
   const float dist_sq = dx * dx + dy * dy + dz * dz;
-  const uint32_t len = (dist_sq > kLodDistSqThreshold) ? mb.len1 : mb.len0;
+  const uint32_t len = (dist_sq > kLodDistSqThreshold) ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
   const bool keep = visible && len > 0u;  // compact_draw_stream.comp:41 `indexCount > 0`
   const uint32_t len_vis = visible ? len : 0u;
 
@@ -560,12 +570,15 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
 
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
-    uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdWords];
+    const bool far_lod = dist_sq > kLodDistSqThreshold;
+    const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
+    uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
     c[0] = len;                                               // indexCount
     c[1] = 1u;                                                // instanceCount, generate_work.comp:63
     c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
-    c[3] = (uint32_t)a.vertex_offset[mesh];                   // vertexOffset, :66
+    c[3] = md.x;                                              // vertexOffset, :66
     c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
+    c[5] = far_lod ? md.z : md.y;                             // push constant indexOffset, cull_pipeline.rs:552
   }
   __syncthreads();  // s_cmd complete
   MIP_STAMP(3);
@@ -588,10 +601,13 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
   const uint32_t words = tile_count * kCmdWords;
   for (uint32_t j = lane; j < words; j += 64u) {
-    uint32_t v = s_cmd[j];
-    if (j % kCmdWords == 2u) v += first_index_add;
+    const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
+    uint32_t v = s_cmd[k * kCmdLdsWords + f];
+    if (f == 2u) v += first_index_add;
     out[j] = v;
   }
+  if (a.src_index_offset)
+    for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
   bulk_stores();
   MIP_STAMP(5);
 }
@@ -649,6 +665,150 @@ __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeAr
     if (field == 2u) v += s_index_base[chunk];
     a.out_cmds[j] = v;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// row f-1: per-triangle cull + index-stream append (src/shaders/generate_work.comp:68-200)
+// ---------------------------------------------------------------------------------------
+// The reference records one dispatch per visible instance (cull_pipeline.rs:536-577). Here
+// one launch walks the compacted command list: ONE WAVE PER COMMAND, 64 triangles per
+// step, the running survivor count in a register — no inter-wave communication, and the
+// surviving triangles keep their mesh order (the stable member of the reference's
+// outcome set; its workgroups append in atomicAdd arrival order, :176-186).
+// Arithmetic: clip = pv * (model * vec4(v,1)) as column combinations left to right, no
+// FMA; back-face = determinant of the xyw columns > 0; x/y NDC rejection after a true
+// divide — exactly what the oracle (orc_cull_triangles) fixes where GLSL leaves it open.
+
+struct TriangleArgs {
+  uint32_t* cmds;                 // compacted commands of the instance kernel; indexCount is rewritten
+  const uint32_t* count;          // number of commands (device)
+  const uint32_t* src_index_offset;
+  const float4* model;            // n x mat4 of the same frame
+  const float* vertices;          // consolidated positions, packed vec3
+  const uint32_t* indices;        // consolidated indices
+  uint32_t* out_indices;          // culled index stream (uvec3 out_index_buffer[])
+  unsigned long long capacity;    // in indices
+  uint32_t first_instance_base;
+  uint32_t* error_flag;
+  float pv[16];
+};
+
+constexpr uint32_t kErrIndexOverflow = 4u;
+
+__device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x, float y, float z, float w, float (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = m[0 * 4 + r] * x + m[1 * 4 + r] * y + m[2 * 4 + r] * z + m[3 * 4 + r] * w;
+}
+
+__global__ __launch_bounds__(256) void mip_triangle_cull_kernel(const TriangleArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  // readfirstlane makes the command index provably wave-uniform: the command words and the
+  // model matrix are then scalar loads held in SGPRs
+  const uint32_t wave_global = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)));
+  const uint32_t wave_stride = gridDim.x * waves_per_block;
+  const uint32_t count = *a.count;
+  float pv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
+
+  for (uint32_t c = wave_global; c < count; c += wave_stride) {
+    // the command and its model matrix are wave-uniform
+    const uint32_t index_count = a.cmds[c * kCmdWords + 0];
+    const uint32_t first_index = a.cmds[c * kCmdWords + 2];
+    const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
+    const uint32_t instance = a.cmds[c * kCmdWords + 4] - a.first_instance_base;
+    const uint32_t src_tri = a.src_index_offset[c] / 3u;  // index_buffer[indexOffset / 3 + id]
+    const uint32_t n_tris = index_count / 3u;
+    float model[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 col = a.model[(size_t)instance * 4 + q];
+      model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
+    }
+    const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
+    if (!fits && lane == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t dst_tri = (size_t)first_index / 3u;
+    uint32_t survivors = 0;
+
+    for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
+      const uint32_t t = t0 + lane;
+      const bool valid = t < n_tris;
+      const uint32_t* ip = a.indices + (size_t)(src_tri + (valid ? t : 0u)) * 3;
+      const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+      const uint32_t ix[3] = {i0, i1, i2};
+      float clip[3][4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* p = a.vertices + ((long long)vertex_offset + (long long)ix[k]) * 3;
+        float world[4];
+        glsl_mat4_mul_vec4(model, p[0], p[1], p[2], 1.0f, world);
+        glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
+      }
+      const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
+      const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][3];
+      const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][3];
+      const float det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) + a20 * (a01 * a12 - a11 * a02);
+      bool cull = det > 0.0f;
+      const float x0 = clip[0][0] / clip[0][3], y0 = clip[0][1] / clip[0][3];
+      const float x1 = clip[1][0] / clip[1][3], y1 = clip[1][1] / clip[1][3];
+      const float x2 = clip[2][0] / clip[2][3], y2 = clip[2][1] / clip[2][3];
+      cull = cull || (x0 < -1.0f && x1 < -1.0f && x2 < -1.0f) || (x0 > 1.0f && x1 > 1.0f && x2 > 1.0f) ||
+             (y0 < -1.0f && y1 < -1.0f && y2 < -1.0f) || (y0 > 1.0f && y1 > 1.0f && y2 > 1.0f);
+      const bool keep = valid && !cull;
+      const unsigned long long mask = __ballot(keep);
+      if (keep && fits) {
+        uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
+        dst[0] = i0; dst[1] = i1; dst[2] = i2;
+      }
+      survivors += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;  // the command's final indexCount
+  }
+}
+
+// compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
+// dropped, order kept. One workgroup of 1024 threads walks the (already dense) list.
+struct RecompactArgs {
+  const uint32_t* in_cmds;
+  const uint32_t* in_count;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+};
+
+__global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_running;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t count = *a.in_count;
+  if (tid == 0) s_running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < count; base += 1024u) {
+    const uint32_t k = base + tid;
+    const bool valid = k < count;
+    uint32_t w[kCmdWords];
+#pragma unroll
+    for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? a.in_cmds[(size_t)k * kCmdWords + f] : 0u;
+    const bool keep = valid && w[0] > 0u;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = s_running, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+      if (q < wave) before += s_wave[q];
+      total += s_wave[q];
+    }
+    if (keep) {
+      uint32_t* dst = a.out_cmds + (size_t)(before + lanes_below(mask)) * kCmdWords;
+#pragma unroll
+      for (uint32_t f = 0; f < kCmdWords; ++f) dst[f] = w[f];
+    }
+    __syncthreads();
+    if (tid == 0) s_running += total;
+    __syncthreads();
+  }
+  if (tid == 0) *a.out_count = s_running;
 }
 
 }  // namespace mip

@@ -32,7 +32,9 @@ struct MipContext {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     unsigned long long* d_status = nullptr;  // level-0 granules, accumulators, group starts
-    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs)
+    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count
+    uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
+    uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t epoch = 0;
     bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
   };
@@ -45,7 +47,13 @@ struct MipContext {
   float* d_scale = nullptr;
   uint32_t* d_mesh_id = nullptr;
   mip::MeshEntry* d_meshes = nullptr;
-  int32_t* d_vertex_offset = nullptr;
+  mip::MeshDraw* d_mesh_draw = nullptr;
+  // consolidated geometry for the per-triangle stage (row f-1)
+  float* d_vertices = nullptr;
+  uint32_t* d_indices = nullptr;
+  uint32_t n_vertices = 0, n_indices = 0;
+  bool have_geometry = false;
+  int cu_count = 0;
   // look-back state
   size_t status_bytes = 0;
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
@@ -118,6 +126,8 @@ int32_t check_device_error(MipContext* ctx) {
     if (e & mip::kErrTimeout)
       return fail(ctx, MIP_ERR_TIMEOUT,
                   "prefix wait expired (an earlier tile never published); outputs invalid");
+    if (e & mip::kErrIndexOverflow)
+      return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
     return fail(ctx, MIP_ERR_CAPACITY,
                 "a shard's draw list is longer than the exchanged chunk holds; merged list truncated");
   }
@@ -134,10 +144,14 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_scale);
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
-  (void)hipFree(ctx->d_vertex_offset);
+  (void)hipFree(ctx->d_mesh_draw);
+  (void)hipFree(ctx->d_vertices);
+  (void)hipFree(ctx->d_indices);
   for (auto& sl : ctx->slots) {
     (void)hipFree(sl.d_status);
     (void)hipFree(sl.d_scalars);
+    (void)hipFree(sl.d_tmp_cmds);
+    (void)hipFree(sl.d_tmp_src);
   }
   (void)hipFree(ctx->s_model);
   (void)hipFree(ctx->s_bitmap);
@@ -198,7 +212,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMalloc(&ctx->d_scale, cap * 4));
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_id, cap * 4));
     MIP_HIP(ctx, hipMalloc(&ctx->d_meshes, mcap * sizeof(mip::MeshEntry)));
-    MIP_HIP(ctx, hipMalloc(&ctx->d_vertex_offset, mcap * 4));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_draw, mcap * sizeof(mip::MeshDraw)));
+    ctx->cu_count = prop.multiProcessorCount;
     const size_t tiles_cap = tiles_for((uint32_t)cap);
     // smallest group the kernel may pick is 16 tiles (group_shift 4)
     ctx->groups_cap = (uint32_t)((tiles_cap + 15) / 16);
@@ -238,7 +253,7 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   if (!meshes && m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "meshes is NULL");
   if (m > ctx->max_meshes) return fail(ctx, MIP_ERR_CAPACITY, "%u meshes > max_meshes %u", m, ctx->max_meshes);
   std::vector<mip::MeshEntry> entries(m);
-  std::vector<int32_t> voff(m);
+  std::vector<mip::MeshDraw> draw(m);
   for (uint32_t k = 0; k < m; ++k) {
     const MipMesh& s = meshes[k];
     if (s.n_lods < 1 || s.n_lods > MIP_MAX_LODS)
@@ -251,16 +266,40 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
     e.max_x = s.aabb_max[0]; e.max_y = s.aabb_max[1]; e.max_z = s.aabb_max[2];
     e.len0 = s.index_len[0];
     e.len1 = s.n_lods > 1 ? s.index_len[1] : s.index_len[0];
-    voff[k] = s.vertex_offset;
+    draw[k].vertex_offset = s.vertex_offset;
+    draw[k].src_offset0 = s.index_offset[0];
+    draw[k].src_offset1 = s.n_lods > 1 ? s.index_offset[1] : s.index_offset[0];
+    draw[k].pad = 0;
   }
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (m) {
     MIP_HIP(ctx, hipMemcpy(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice));
-    MIP_HIP(ctx, hipMemcpy(ctx->d_vertex_offset, voff.data(), m * 4, hipMemcpyHostToDevice));
+    MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_draw, draw.data(), m * sizeof(mip::MeshDraw), hipMemcpyHostToDevice));
   }
   ctx->m = m;
   ctx->have_meshes = true;
+  return MIP_OK;
+}
+
+int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_vertices, const uint32_t* indices,
+                         uint32_t n_indices) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if ((n_vertices && !vertex_xyz) || (n_indices && !indices)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL geometry");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  (void)hipFree(ctx->d_vertices);
+  (void)hipFree(ctx->d_indices);
+  ctx->d_vertices = nullptr;
+  ctx->d_indices = nullptr;
+  ctx->have_geometry = false;
+  MIP_HIP(ctx, hipMalloc(&ctx->d_vertices, (size_t)(n_vertices ? n_vertices : 1) * 12));
+  MIP_HIP(ctx, hipMalloc(&ctx->d_indices, (size_t)(n_indices ? n_indices : 1) * 4));
+  if (n_vertices) MIP_HIP(ctx, hipMemcpy(ctx->d_vertices, vertex_xyz, (size_t)n_vertices * 12, hipMemcpyHostToDevice));
+  if (n_indices) MIP_HIP(ctx, hipMemcpy(ctx->d_indices, indices, (size_t)n_indices * 4, hipMemcpyHostToDevice));
+  ctx->n_vertices = n_vertices;
+  ctx->n_indices = n_indices;
+  ctx->have_geometry = true;
   return MIP_OK;
 }
 
@@ -314,6 +353,12 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   const bool async = device_out && (out->flags & MIP_OUT_ASYNC) != 0;
   if ((out->flags & MIP_OUT_ASYNC) && !device_out)
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
+  const bool triangles = out->culled_index_buffer != nullptr;
+  if (triangles) {
+    if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
+    if (!ctx->have_geometry) return fail(ctx, MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
+    if (!out->model || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs model and draw_cmds");
+  }
   if (int32_t rc = bind_device(ctx)) return rc;
 
   // Frames rotate over the slots; a slot's stream orders a frame after the frame that last
@@ -329,13 +374,23 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
 
   mip::KernelArgs a{};
   a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
-  a.meshes = ctx->d_meshes; a.vertex_offset = ctx->d_vertex_offset;
+  a.meshes = ctx->d_meshes; a.mesh_draw = ctx->d_mesh_draw;
   a.model = out->model ? (device_out ? (float4*)out->model : ctx->s_model) : nullptr;
   a.bitmap = out->visible_bitmap ? (device_out ? out->visible_bitmap : ctx->s_bitmap) : nullptr;
   a.cmds = out->draw_cmds ? (device_out ? (uint32_t*)out->draw_cmds : ctx->s_cmds) : nullptr;
   a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : sl.d_scalars + 0) : nullptr;
   a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : sl.d_scalars + 1) : nullptr;
   a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
+  if (triangles) {
+    // the instance kernel emits into the slot's scratch list; the triangle stage rewrites
+    // indexCount there and the final compaction lands in the caller's buffers
+    const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
+    if (!sl.d_tmp_cmds) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_cmds, cap * 20));
+    if (!sl.d_tmp_src) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_src, cap * 4));
+    a.cmds = sl.d_tmp_cmds;
+    a.draw_count = sl.d_scalars + 2;
+    a.src_index_offset = sl.d_tmp_src;
+  }
   a.status0 = sl.d_status;
   a.acc1 = sl.d_status + ctx->acc1_offset_words;
   a.start1 = sl.d_status + ctx->start1_offset_words;
@@ -368,12 +423,40 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
 
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0;
   if (n == 0) {
+    if (triangles) MIP_HIP(ctx, hipMemsetAsync(out->draw_count, 0, 4, stream));
     if (a.draw_count) MIP_HIP(ctx, hipMemsetAsync(a.draw_count, 0, 4, stream));
     if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, stream));
   } else {
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, stream, a);
     MIP_HIP(ctx, hipGetLastError());
+    if (triangles) {
+      mip::TriangleArgs t{};
+      t.cmds = sl.d_tmp_cmds;
+      t.count = sl.d_scalars + 2;
+      t.src_index_offset = sl.d_tmp_src;
+      t.model = (const float4*)out->model;
+      t.vertices = ctx->d_vertices;
+      t.indices = ctx->d_indices;
+      t.out_indices = (uint32_t*)out->culled_index_buffer;
+      t.capacity = out->culled_index_capacity;
+      t.first_instance_base = frame->first_instance_base;
+      t.error_flag = ctx->d_error;
+      std::memcpy(t.pv, frame->pv, sizeof t.pv);
+      // one wave per command; the command count lives on the device, so size for the worst case
+      uint32_t blocks = (n + 3u) / 4u;
+      const uint32_t max_blocks = (uint32_t)ctx->cu_count * 8u;
+      if (blocks > max_blocks) blocks = max_blocks;
+      hipLaunchKernelGGL(mip::mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, t);
+      MIP_HIP(ctx, hipGetLastError());
+      mip::RecompactArgs r{};
+      r.in_cmds = sl.d_tmp_cmds;
+      r.in_count = sl.d_scalars + 2;
+      r.out_cmds = (uint32_t*)out->draw_cmds;
+      r.out_count = out->draw_count;
+      hipLaunchKernelGGL(mip::mip_recompact_kernel, dim3(1), dim3(1024), 0, stream, r);
+      MIP_HIP(ctx, hipGetLastError());
+    }
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, stream));
   }
 

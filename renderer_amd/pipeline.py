@@ -30,8 +30,10 @@ DRAW_CMD_DTYPE = np.dtype(
 SHARD_HEADER_BYTES = 32
 
 
-def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0):
+def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0, pv=None):
     f = MipFrame()
+    if pv is not None:
+        f.pv[:] = np.ascontiguousarray(pv, dtype=np.float32).reshape(16).tolist()
     planes = np.ascontiguousarray(planes, dtype=np.float32).reshape(24)
     cam_pos = np.ascontiguousarray(cam_pos, dtype=np.float32).reshape(3)
     f.planes[:] = planes.tolist()
@@ -102,6 +104,12 @@ class InstancePipeline:
                                                 scl.ctypes.data, mid.ctypes.data, n))
         self.n = n
 
+    def set_geometry(self, vertex_xyz, indices):
+        """Consolidated position / index buffers for the per-triangle stage."""
+        v = np.ascontiguousarray(vertex_xyz, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        self._check(self._lib.mip_set_geometry(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)))
+
     def set_instances_device(self, pos_ptr, rot_ptr, scale_ptr, mesh_id_ptr, n):
         self._check(self._lib.mip_set_instances_device(self._ctx, pos_ptr, rot_ptr, scale_ptr,
                                                        mesh_id_ptr, int(n)))
@@ -141,7 +149,7 @@ class InstancePipeline:
         return res
 
     def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0,
-                   draw_index_total=0, world_aabb=0, async_=False):
+                   draw_index_total=0, world_aabb=0, async_=False, culled_index_buffer=0, culled_index_capacity=0):
         """Device pointers in, nothing copied. `frame` from make_frame()."""
         out = MipOutputs()
         out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
@@ -151,10 +159,12 @@ class InstancePipeline:
         out.draw_count = draw_count or None
         out.draw_index_total = draw_index_total or None
         out.world_aabb = world_aabb or None
+        out.culled_index_buffer = culled_index_buffer or None
+        out.culled_index_capacity = int(culled_index_capacity)
         self._check(self._lib.mip_run(self._ctx, C.byref(frame), C.byref(out)))
 
     def prepare_outputs(self, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0, draw_index_total=0,
-                        world_aabb=0, async_=True):
+                        world_aabb=0, async_=True, culled_index_buffer=0, culled_index_capacity=0):
         """A reusable MipOutputs (device pointers) for run_prepared: keeps the per-frame host cost
         to one foreign call."""
         out = MipOutputs()
@@ -165,6 +175,8 @@ class InstancePipeline:
         out.draw_count = draw_count or None
         out.draw_index_total = draw_index_total or None
         out.world_aabb = world_aabb or None
+        out.culled_index_buffer = culled_index_buffer or None
+        out.culled_index_capacity = int(culled_index_capacity)
         out._as_parameter_ = C.c_void_p(C.addressof(out))  # lets ctypes pass the struct by address
         return out
 

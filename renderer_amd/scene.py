@@ -167,3 +167,91 @@ def make_scene(config, n=None, first=0, all_visible=False):
     return dict(config=config, name=cfg["name"], workload=cfg["workload"], n=n, meshes=meshes,
                 pos=pos, rot=rot, scale=scale, mesh_id=mesh, planes=default_planes(),
                 cam_pos=np.asarray(DEFAULT_CAMERA["cam_pos"], np.float32))
+
+
+# ---- synthetic geometry for the per-triangle stage (row f-1) --------------------------------
+
+def default_pv():
+    """CameraMatrices.pv = projection * view of the reference's default camera, float32[16]
+    column-major (float64 arithmetic, rounded once), consistent with default_planes()."""
+    c = DEFAULT_CAMERA
+    t = np.tan(np.radians(c["fovy_degrees"]) / 2.0)
+    n, f = c["near"], c["far"]
+    proj = np.zeros((4, 4))
+    proj[0, 0] = 1.0 / (c["aspect"] * t)
+    proj[1, 1] = 1.0 / t
+    proj[2, 2] = f / (f - n)
+    proj[2, 3] = -(f * n) / (f - n)
+    proj[3, 2] = 1.0
+    view = np.eye(4)
+    view[:3, 3] = -np.array(c["cam_pos"], dtype=np.float64)
+    return (proj @ view).T.astype(np.float32).reshape(16)  # .T: row-major array -> column-major storage
+
+
+def _torus_mesh(n_vertices, n_triangles, aabb_min, aabb_max):
+    """A closed, consistently wound surface (torus grid) with exactly n_vertices positions and
+    n_triangles triangles, inside the given box."""
+    w = max(3, int(np.sqrt(n_vertices)))
+    h = max(3, n_vertices // w)
+    while w * h > n_vertices and h > 3:
+        h -= 1
+    if w * h > n_vertices:  # tiny meshes: fall back to a 3x3 patch, extra triangles reuse it
+        w = h = 3
+    u = (np.arange(w) / w) * 2 * np.pi
+    v = (np.arange(h) / h) * 2 * np.pi
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    big, small = 0.7, 0.3
+    x = (big + small * np.cos(vv)) * np.cos(uu)
+    y = small * np.sin(vv)
+    z = (big + small * np.cos(vv)) * np.sin(uu)
+    pts = np.stack([x, y / small * 1.0 * small, z], axis=-1).reshape(-1, 3)  # in [-1,1] x [-0.3,0.3] x [-1,1]
+    pts[:, 1] /= small  # stretch y to [-1, 1]
+    centre = (np.asarray(aabb_max, np.float64) + np.asarray(aabb_min, np.float64)) / 2
+    half = (np.asarray(aabb_max, np.float64) - np.asarray(aabb_min, np.float64)) / 2
+    pos = np.zeros((max(n_vertices, w * h), 3))
+    pos[: w * h] = centre + pts * half
+    pos[w * h :] = centre
+    pos = pos[: max(n_vertices, w * h)]
+    i, j = np.meshgrid(np.arange(w), np.arange(h), indexing="ij")
+    a = (i * h + j).reshape(-1)
+    b = (((i + 1) % w) * h + j).reshape(-1)
+    c = (((i + 1) % w) * h + (j + 1) % h).reshape(-1)
+    d = (i * h + (j + 1) % h).reshape(-1)
+    tris = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], axis=0)
+    order = (np.arange(n_triangles, dtype=np.int64) * len(tris)) // max(n_triangles, 1) if n_triangles <= len(tris) \
+        else np.arange(n_triangles, dtype=np.int64) % len(tris)
+    return pos.astype(np.float32), tris[order].astype(np.uint32)
+
+
+def make_geometry(meshes):
+    """Consolidated position and index buffers matching a mesh table's vertex_offset /
+    index_offset / index_len (what consolidate_mesh_buffers builds). Returns (vertices (V,3) f32,
+    indices (I,) u32). LOD k keeps an evenly spaced subset of LOD 0's triangles."""
+    m = len(meshes)
+    voff = meshes["vertex_offset"].astype(np.int64)
+    order = np.argsort(voff, kind="stable")
+    vcount = np.zeros(m, np.int64)
+    for rank, k in enumerate(order):
+        nxt = voff[order[rank + 1]] if rank + 1 < m else None
+        len0 = int(meshes["index_len"][k, 0])
+        vcount[k] = (nxt - voff[k]) if nxt is not None and nxt > voff[k] else max(len0 // 3, 9)
+    total_v = int((voff + vcount).max()) if m else 0
+    total_i = 0
+    for k in range(m):
+        for l in range(int(meshes["n_lods"][k])):
+            total_i = max(total_i, int(meshes["index_offset"][k, l]) + int(meshes["index_len"][k, l]))
+    vertices = np.zeros((total_v, 3), np.float32)
+    indices = np.zeros(total_i, np.uint32)
+    for k in range(m):
+        t0 = int(meshes["index_len"][k, 0]) // 3
+        pos, tris = _torus_mesh(int(vcount[k]), max(t0, 1), meshes["aabb_min"][k], meshes["aabb_max"][k])
+        vertices[voff[k] : voff[k] + vcount[k]] = pos[: vcount[k]]
+        tris = np.minimum(tris, vcount[k] - 1)
+        for l in range(int(meshes["n_lods"][k])):
+            tl = int(meshes["index_len"][k, l]) // 3
+            if tl == 0:
+                continue
+            pick = (np.arange(tl, dtype=np.int64) * max(t0, 1)) // tl if t0 else np.zeros(tl, np.int64)
+            off = int(meshes["index_offset"][k, l])
+            indices[off : off + tl * 3] = tris[pick % len(tris)].reshape(-1)
+    return vertices, indices
