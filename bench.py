@@ -163,6 +163,64 @@ def cpu_baseline(scene_dict, seconds):
     }
 
 
+def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, with_cpu):
+    """generate_work.comp:68-200 for every emitted command of the headline scene (synthetic torus
+    geometry with the DamagedHelmet triangle counts): frame = instance kernel + triangle kernel +
+    re-compaction."""
+    n = s["n"]
+    vertices, indices = scene.make_geometry(s["meshes"])
+    pv = scene.default_pv()
+    p = renderer_amd.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), device=local_rank)
+    p.set_mesh_table(s["meshes"])
+    p.set_geometry(vertices, indices)
+    p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    o = DeviceOutputs(torch, n, device)
+    frame = make_frame(s["planes"], s["cam_pos"], pv=pv)
+    p.run_device(frame, **o.kwargs())
+    count0, total = (int(x) & 0xFFFFFFFF for x in o.scalars[:2].cpu().tolist())
+    tris_in = int(o.cmds[:count0, 0].to(torch.int64).sum().item()) // 3
+    stream_out = torch.empty(total + 3, dtype=torch.int32, device=device)
+    kw = dict(o.kwargs(), culled_index_buffer=stream_out.data_ptr(), culled_index_capacity=total + 3)
+    for _ in range(3):
+        p.run_device(frame, **kw)
+    count1 = int(o.scalars[0].item())
+    tris_out = int(o.cmds[:count1, 0].to(torch.int64).sum().item()) // 3
+    steps = 20
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.run_device(frame, async_=True, **kw)
+    p.wait()
+    dt = (time.perf_counter() - t0) / steps
+    p.close()
+    row = {
+        "instances": n, "commands_in": count0, "commands_out": count1, "triangles_in": tris_in,
+        "triangles_surviving": tris_out, "ms_per_frame": dt * 1e3, "triangles_per_s": tris_in / dt,
+        "index_stream_write_GBps": tris_out * 12 / dt / 1e9,
+        "note": "VALU-bound (two mat4*vec4 per vertex without FMA + 6 correctly rounded divides per triangle); "
+                "geometry is L2-resident, HBM traffic is the 12 B per surviving triangle",
+    }
+    if with_cpu:
+        import oracle
+
+        cores = host_cores()
+        sample = min(n, 4000)
+        s2 = {k: (v[:sample] if k in ("pos", "rot", "scale", "mesh_id") else v) for k, v in s.items()}
+        r = oracle.run(s2["pos"], s2["rot"], s2["scale"], s2["mesh_id"], s2["meshes"], s2["planes"], s2["cam_pos"], threads=cores)
+        t_in = int(r["draw_cmds"]["indexCount"].astype(np.int64).sum()) // 3
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            oracle.cull_all_triangles(r, s2["pos"], s2["mesh_id"], s2["meshes"], s2["cam_pos"], pv, vertices, indices, threads=cores)
+            passes += 1
+            dtc = time.perf_counter() - t0
+            if dtc >= 3.0 or passes >= 500:
+                break
+        row["cpu_baseline"] = {"value": t_in * passes / dtc, "unit": "triangles/s", "cores": cores, "kind": "port",
+                               "sample": f"{passes} passes over the commands of the first {sample} instances ({t_in} triangles each), "
+                                         f"{cores} threads, {dtc:.1f} s wall"}
+    return row
+
+
 def main():
     args = parse_args()
     import torch
@@ -358,6 +416,11 @@ def main():
                 del o2
             extra[label] = row
         result["extra"] = extra
+
+    if not args.no_extra and not distributed and args.config == 2 and args.instances is None and rank == 0:
+        # row f-1 (next tier, not the headline): per-triangle cull + index-stream append on the same scene
+        result.setdefault("extra", {})["triangle_cull"] = triangle_leg(torch, renderer_amd, scene, make_frame, s, device,
+                                                                        local_rank, not args.no_cpu_baseline)
 
     if distributed and not args.no_extra:
         # the exchange regime (BASELINE config 4's shape): 1.25 M instances per rank, one RCCL
