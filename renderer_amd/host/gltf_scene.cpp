@@ -1,0 +1,446 @@
+// gltf_scene.cpp — see gltf_scene.hpp.
+#include "gltf_scene.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+
+namespace renderer {
+namespace gltf {
+namespace {
+
+// ------------------------------------------------------------------ minimal JSON
+struct Json {
+  enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+  bool b = false;
+  double num = 0;
+  std::string str;
+  std::vector<Json> arr;
+  std::vector<std::pair<std::string, Json>> obj;
+
+  const Json* get(const char* key) const {
+    if (kind != Object) return nullptr;
+    for (const auto& kv : obj)
+      if (kv.first == key) return &kv.second;
+    return nullptr;
+  }
+  bool has(const char* key) const { return get(key) != nullptr; }
+  double number_or(const char* key, double d) const {
+    const Json* j = get(key);
+    return (j && j->kind == Number) ? j->num : d;
+  }
+  size_t size() const { return kind == Array ? arr.size() : 0; }
+};
+
+struct Parser {
+  const std::string& s;
+  size_t i = 0;
+  explicit Parser(const std::string& text) : s(text) {}
+  [[noreturn]] void fail(const char* what) const {
+    throw std::runtime_error(std::string("gltf json: ") + what + " at byte " + std::to_string(i));
+  }
+  void ws() {
+    while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\r' || s[i] == '\t')) ++i;
+  }
+  Json value() {
+    ws();
+    if (i >= s.size()) fail("unexpected end");
+    const char c = s[i];
+    if (c == '{') return object();
+    if (c == '[') return array();
+    if (c == '"') {
+      Json j;
+      j.kind = Json::String;
+      j.str = string();
+      return j;
+    }
+    if (!s.compare(i, 4, "true")) { i += 4; Json j; j.kind = Json::Bool; j.b = true; return j; }
+    if (!s.compare(i, 5, "false")) { i += 5; Json j; j.kind = Json::Bool; return j; }
+    if (!s.compare(i, 4, "null")) { i += 4; return Json(); }
+    return number();
+  }
+  Json number() {
+    const size_t start = i;
+    while (i < s.size() && (std::isdigit((unsigned char)s[i]) || s[i] == '-' || s[i] == '+' || s[i] == '.' || s[i] == 'e' || s[i] == 'E')) ++i;
+    if (start == i) fail("bad token");
+    Json j;
+    j.kind = Json::Number;
+    j.num = std::strtod(s.substr(start, i - start).c_str(), nullptr);
+    return j;
+  }
+  std::string string() {
+    ++i;  // opening quote
+    std::string out;
+    while (i < s.size() && s[i] != '"') {
+      if (s[i] == '\\') {
+        ++i;
+        if (i >= s.size()) fail("bad escape");
+        switch (s[i]) {
+          case 'n': out += '\n'; break;
+          case 't': out += '\t'; break;
+          case 'r': out += '\r'; break;
+          case 'b': out += '\b'; break;
+          case 'f': out += '\f'; break;
+          case 'u': {  // keep BMP code points as UTF-8; enough for names and URIs
+            if (i + 4 >= s.size()) fail("bad \\u");
+            const unsigned cp = (unsigned)std::strtoul(s.substr(i + 1, 4).c_str(), nullptr, 16);
+            i += 4;
+            if (cp < 0x80) out += (char)cp;
+            else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+            else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+            break;
+          }
+          default: out += s[i];
+        }
+        ++i;
+      } else {
+        out += s[i++];
+      }
+    }
+    if (i >= s.size()) fail("unterminated string");
+    ++i;
+    return out;
+  }
+  Json array() {
+    Json j;
+    j.kind = Json::Array;
+    ++i;
+    ws();
+    if (i < s.size() && s[i] == ']') { ++i; return j; }
+    for (;;) {
+      j.arr.push_back(value());
+      ws();
+      if (i >= s.size()) fail("unterminated array");
+      if (s[i] == ',') { ++i; continue; }
+      if (s[i] == ']') { ++i; return j; }
+      fail("expected , or ]");
+    }
+  }
+  Json object() {
+    Json j;
+    j.kind = Json::Object;
+    ++i;
+    ws();
+    if (i < s.size() && s[i] == '}') { ++i; return j; }
+    for (;;) {
+      ws();
+      if (i >= s.size() || s[i] != '"') fail("expected key");
+      std::string key = string();
+      ws();
+      if (i >= s.size() || s[i] != ':') fail("expected :");
+      ++i;
+      j.obj.emplace_back(std::move(key), value());
+      ws();
+      if (i >= s.size()) fail("unterminated object");
+      if (s[i] == ',') { ++i; continue; }
+      if (s[i] == '}') { ++i; return j; }
+      fail("expected , or }");
+    }
+  }
+};
+
+// ------------------------------------------------------------------ buffers
+std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("gltf: cannot open " + path);
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+std::string base64_decode(const std::string& in, size_t start) {
+  static int table[256];
+  static bool init = false;
+  if (!init) {
+    for (int k = 0; k < 256; ++k) table[k] = -1;
+    const char* abc = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    for (int k = 0; k < 64; ++k) table[(unsigned char)abc[k]] = k;
+    init = true;
+  }
+  std::string out;
+  unsigned acc = 0;
+  int bits = 0;
+  for (size_t k = start; k < in.size(); ++k) {
+    const int v = table[(unsigned char)in[k]];
+    if (v < 0) continue;  // '=', whitespace
+    acc = (acc << 6) | (unsigned)v;
+    bits += 6;
+    if (bits >= 8) {
+      bits -= 8;
+      out += (char)((acc >> bits) & 0xFF);
+    }
+  }
+  return out;
+}
+
+std::string dirname_of(const std::string& path) {
+  const size_t slash = path.find_last_of('/');
+  return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+
+struct Document {
+  Json root;
+  std::vector<std::string> buffers;
+};
+
+Document open_document(const std::string& path) {
+  Document d;
+  std::string text = read_file(path);
+  std::string glb_bin;
+  bool have_glb_bin = false;
+  if (text.size() >= 20 && !text.compare(0, 4, "glTF")) {  // .glb: 12-byte header, JSON chunk, optional BIN chunk
+    uint32_t json_len;
+    std::memcpy(&json_len, &text[12], 4);
+    if (text.compare(16, 4, "JSON") || 20 + (size_t)json_len > text.size()) throw std::runtime_error("gltf: malformed glb");
+    const std::string json = text.substr(20, json_len);
+    size_t at = 20 + json_len;
+    if (at + 8 <= text.size()) {
+      uint32_t bin_len;
+      std::memcpy(&bin_len, &text[at], 4);
+      if (!text.compare(at + 4, 3, "BIN") && at + 8 + bin_len <= text.size()) {
+        glb_bin = text.substr(at + 8, bin_len);
+        have_glb_bin = true;
+      }
+    }
+    text = json;
+  }
+  Parser p(text);
+  d.root = p.value();
+  if (d.root.kind != Json::Object) throw std::runtime_error("gltf: top level is not an object");
+  const Json* buffers = d.root.get("buffers");
+  for (size_t k = 0; buffers && k < buffers->size(); ++k) {
+    const Json& b = buffers->arr[k];
+    const Json* uri = b.get("uri");
+    if (!uri) {
+      if (k == 0 && have_glb_bin) d.buffers.push_back(glb_bin);
+      else throw std::runtime_error("gltf: buffer without uri");
+    } else if (!uri->str.compare(0, 5, "data:")) {
+      const size_t comma = uri->str.find(',');
+      if (comma == std::string::npos) throw std::runtime_error("gltf: bad data uri");
+      d.buffers.push_back(base64_decode(uri->str, comma + 1));
+    } else {
+      d.buffers.push_back(read_file(dirname_of(path) + "/" + uri->str));
+    }
+  }
+  return d;
+}
+
+// ------------------------------------------------------------------ accessors
+struct AccessorView {
+  const unsigned char* data = nullptr;
+  size_t count = 0, stride = 0;
+  int component_type = 0, components = 0;
+};
+
+int component_size(int type) {
+  switch (type) {
+    case 5120: case 5121: return 1;
+    case 5122: case 5123: return 2;
+    case 5125: case 5126: return 4;
+  }
+  throw std::runtime_error("gltf: unknown componentType");
+}
+
+AccessorView view_of(const Document& d, size_t accessor_index) {
+  const Json* accessors = d.root.get("accessors");
+  if (!accessors || accessor_index >= accessors->size()) throw std::runtime_error("gltf: accessor index out of range");
+  const Json& a = accessors->arr[accessor_index];
+  if (a.has("sparse")) throw std::runtime_error("gltf: sparse accessors are not supported");
+  const Json* bv_index = a.get("bufferView");
+  if (!bv_index) throw std::runtime_error("gltf: accessor without bufferView");
+  const Json* views = d.root.get("bufferViews");
+  if (!views || (size_t)bv_index->num >= views->size()) throw std::runtime_error("gltf: bufferView index out of range");
+  const Json& bv = views->arr[(size_t)bv_index->num];
+  const size_t buffer = (size_t)bv.number_or("buffer", 0);
+  if (buffer >= d.buffers.size()) throw std::runtime_error("gltf: buffer index out of range");
+  AccessorView v;
+  v.component_type = (int)a.number_or("componentType", 0);
+  const Json* type = a.get("type");
+  const std::string t = type ? type->str : "";
+  v.components = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : 0;
+  if (!v.components) throw std::runtime_error("gltf: unsupported accessor type " + t);
+  v.count = (size_t)a.number_or("count", 0);
+  const size_t elem = (size_t)component_size(v.component_type) * v.components;
+  v.stride = (size_t)bv.number_or("byteStride", 0);
+  if (!v.stride) v.stride = elem;
+  const size_t offset = (size_t)bv.number_or("byteOffset", 0) + (size_t)a.number_or("byteOffset", 0);
+  const std::string& buf = d.buffers[buffer];
+  if (v.count && offset + (v.count - 1) * v.stride + elem > buf.size()) throw std::runtime_error("gltf: accessor overruns its buffer");
+  v.data = (const unsigned char*)buf.data() + offset;
+  return v;
+}
+
+// ------------------------------------------------------------------ node transform
+// gltf crate Transform::decomposed(): TRS as stored; a matrix is split into translation,
+// per-axis scale (column lengths, z signed by the determinant) and a quaternion.
+void decompose(const Json& node, float t[3], float r[4], float s[3]) {
+  t[0] = t[1] = t[2] = 0;
+  r[0] = r[1] = r[2] = 0; r[3] = 1;
+  s[0] = s[1] = s[2] = 1;
+  if (const Json* m = node.get("matrix")) {
+    if (m->size() != 16) throw std::runtime_error("gltf: node.matrix needs 16 numbers");
+    double c[3][3];
+    for (int col = 0; col < 3; ++col)
+      for (int row = 0; row < 3; ++row) c[col][row] = m->arr[col * 4 + row].num;
+    for (int k = 0; k < 3; ++k) t[k] = (float)m->arr[12 + k].num;
+    const double det = c[0][0] * (c[1][1] * c[2][2] - c[2][1] * c[1][2]) - c[1][0] * (c[0][1] * c[2][2] - c[2][1] * c[0][2]) +
+                       c[2][0] * (c[0][1] * c[1][2] - c[1][1] * c[0][2]);
+    double len[3];
+    for (int k = 0; k < 3; ++k) len[k] = std::sqrt(c[k][0] * c[k][0] + c[k][1] * c[k][1] + c[k][2] * c[k][2]);
+    if (det < 0) len[2] = -len[2];
+    for (int k = 0; k < 3; ++k) {
+      s[k] = (float)len[k];
+      for (int row = 0; row < 3; ++row) c[k][row] = len[k] != 0 ? c[k][row] / len[k] : 0.0;
+    }
+    // rotation matrix (columns c[k]) -> quaternion, trace method
+    const double m00 = c[0][0], m11 = c[1][1], m22 = c[2][2];
+    const double trace = m00 + m11 + m22;
+    double x, y, z, w;
+    if (trace > 0) {
+      const double q = std::sqrt(trace + 1.0) * 2;
+      w = q / 4; x = (c[1][2] - c[2][1]) / q; y = (c[2][0] - c[0][2]) / q; z = (c[0][1] - c[1][0]) / q;
+    } else if (m00 > m11 && m00 > m22) {
+      const double q = std::sqrt(1.0 + m00 - m11 - m22) * 2;
+      w = (c[1][2] - c[2][1]) / q; x = q / 4; y = (c[1][0] + c[0][1]) / q; z = (c[2][0] + c[0][2]) / q;
+    } else if (m11 > m22) {
+      const double q = std::sqrt(1.0 + m11 - m00 - m22) * 2;
+      w = (c[2][0] - c[0][2]) / q; x = (c[1][0] + c[0][1]) / q; y = q / 4; z = (c[2][1] + c[1][2]) / q;
+    } else {
+      const double q = std::sqrt(1.0 + m22 - m00 - m11) * 2;
+      w = (c[0][1] - c[1][0]) / q; x = (c[2][0] + c[0][2]) / q; y = (c[2][1] + c[1][2]) / q; z = q / 4;
+    }
+    r[0] = (float)x; r[1] = (float)y; r[2] = (float)z; r[3] = (float)w;
+    return;
+  }
+  if (const Json* j = node.get("translation"))
+    for (int k = 0; k < 3 && (size_t)k < j->size(); ++k) t[k] = (float)j->arr[k].num;
+  if (const Json* j = node.get("rotation"))
+    for (int k = 0; k < 4 && (size_t)k < j->size(); ++k) r[k] = (float)j->arr[k].num;  // glTF [x,y,z,w] = [i,j,k,w]
+  if (const Json* j = node.get("scale"))
+    for (int k = 0; k < 3 && (size_t)k < j->size(); ++k) s[k] = (float)j->arr[k].num;
+}
+
+bool has_base_color_texture(const Document& d, const Json& primitive) {
+  const Json* mat_index = primitive.get("material");
+  const Json* materials = d.root.get("materials");
+  if (!mat_index || !materials || (size_t)mat_index->num >= materials->size()) return false;
+  const Json* pbr = materials->arr[(size_t)mat_index->num].get("pbrMetallicRoughness");
+  return pbr && pbr->has("baseColorTexture");
+}
+
+void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
+  const Json* nodes = d.root.get("nodes");
+  if (!nodes || node_index >= nodes->size()) throw std::runtime_error("gltf: node index out of range");
+  if (depth > 256) throw std::runtime_error("gltf: node hierarchy too deep (cycle?)");
+  const Json& node = nodes->arr[node_index];
+  if (const Json* mesh_index = node.get("mesh")) {
+    const Json* meshes = d.root.get("meshes");
+    if (!meshes || (size_t)mesh_index->num >= meshes->size()) throw std::runtime_error("gltf: mesh index out of range");
+    const Json& mesh = meshes->arr[(size_t)mesh_index->num];
+    const Json* primitives = mesh.get("primitives");
+    for (size_t p = 0; primitives && p < primitives->size(); ++p) {
+      const Json& prim = primitives->arr[p];
+      ++out.primitives_seen;
+      if (!has_base_color_texture(d, prim)) {  // scene_loader.rs:659-667
+        ++out.skipped_no_base_color;
+        continue;
+      }
+      const Json* attributes = prim.get("attributes");
+      const Json* pos_acc = attributes ? attributes->get("POSITION") : nullptr;
+      if (!pos_acc) throw std::runtime_error("gltf: primitive without POSITION");  // "failed to load positions"
+      const AccessorView positions = view_of(d, (size_t)pos_acc->num);
+      if (positions.component_type != 5126 || positions.components != 3) throw std::runtime_error("gltf: POSITION must be float VEC3");
+      if (positions.count < 100) {  // :677-679
+        ++out.skipped_small;
+        continue;
+      }
+      const Json& pos_json = d.root.get("accessors")->arr[(size_t)pos_acc->num];
+      const Json* mn = pos_json.get("min");
+      const Json* mx = pos_json.get("max");
+      if (!mn || !mx || mn->size() != 3 || mx->size() != 3) throw std::runtime_error("gltf: POSITION accessor needs min/max");
+      const Json* idx_acc = prim.get("indices");
+      if (!idx_acc) throw std::runtime_error("gltf: primitive without indices");  // "failed to load indices"
+      const AccessorView idx = view_of(d, (size_t)idx_acc->num);
+      if (idx.components != 1) throw std::runtime_error("gltf: indices must be SCALAR");
+
+      MipMesh m{};
+      for (int k = 0; k < 3; ++k) {
+        m.aabb_min[k] = (float)mn->arr[k].num;
+        m.aabb_max[k] = (float)mx->arr[k].num;
+      }
+      m.vertex_offset = (int32_t)(out.vertices.size() / 3);
+      for (size_t v = 0; v < positions.count; ++v) {
+        float xyz[3];
+        std::memcpy(xyz, positions.data + v * positions.stride, 12);
+        out.vertices.insert(out.vertices.end(), xyz, xyz + 3);
+      }
+      std::vector<uint32_t> lod0(idx.count);
+      for (size_t k = 0; k < idx.count; ++k) {
+        const unsigned char* e = idx.data + k * idx.stride;
+        uint32_t v = 0;
+        if (idx.component_type == 5121) v = e[0];
+        else if (idx.component_type == 5123) { uint16_t h; std::memcpy(&h, e, 2); v = h; }
+        else if (idx.component_type == 5125) std::memcpy(&v, e, 4);
+        else throw std::runtime_error("gltf: indices must be unsigned");
+        lod0[k] = v;
+      }
+      // LOD chain (:740-753): LOD 0 + up to five reduced levels kept while they shrink and are non-empty
+      std::vector<std::vector<uint32_t>> lods;
+      lods.push_back(lod0);
+      const size_t tris0 = lod0.size() / 3;
+      for (int x = 1; x < 6; ++x) {
+        const float factor = std::pow(0.5f, (float)x);
+        size_t target = (size_t)((float)lod0.size() * factor);
+        target -= target % 3;
+        if (target == 0 || target >= lod0.size()) continue;
+        std::vector<uint32_t> lod(target);
+        const size_t tris = target / 3;
+        for (size_t t = 0; t < tris; ++t) {
+          const size_t src = (t * tris0) / tris;
+          lod[t * 3 + 0] = lod0[src * 3 + 0];
+          lod[t * 3 + 1] = lod0[src * 3 + 1];
+          lod[t * 3 + 2] = lod0[src * 3 + 2];
+        }
+        lods.push_back(std::move(lod));
+      }
+      m.n_lods = (uint32_t)lods.size();
+      for (size_t l = 0; l < lods.size(); ++l) {
+        m.index_len[l] = (uint32_t)lods[l].size();
+        m.index_offset[l] = (uint32_t)out.indices.size();
+        out.indices.insert(out.indices.end(), lods[l].begin(), lods[l].end());
+      }
+      float t[3], r[4], s[3];
+      decompose(node, t, r, s);
+      out.pos_xyz.insert(out.pos_xyz.end(), t, t + 3);
+      out.rot_ijkw.insert(out.rot_ijkw.end(), r, r + 4);
+      out.scale.push_back(s[0]);  // scale: scale[0], :765
+      out.mesh_id.push_back((uint32_t)out.meshes.size());
+      out.meshes.push_back(m);
+      const Json* name = node.get("name");
+      out.entity_names.push_back(name ? name->str : std::string());
+    }
+  }
+  if (const Json* children = node.get("children"))
+    for (size_t k = 0; k < children->size(); ++k) visit_node(d, (size_t)children->arr[k].num, out, depth + 1);
+}
+
+}  // namespace
+
+Scene load(const std::string& path) {
+  const Document d = open_document(path);
+  Scene out;
+  const Json* scenes = d.root.get("scenes");
+  for (size_t s = 0; scenes && s < scenes->size(); ++s) {  // every scene, every root node (:137-142)
+    const Json* roots = scenes->arr[s].get("nodes");
+    for (size_t k = 0; roots && k < roots->size(); ++k) visit_node(d, (size_t)roots->arr[k].num, out, 0);
+  }
+  return out;
+}
+
+}  // namespace gltf
+}  // namespace renderer
