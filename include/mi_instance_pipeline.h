@@ -142,6 +142,13 @@ typedef struct MipOutputs {
    * index_len of the earlier commands. */
   void* culled_index_buffer;
   uint64_t culled_index_capacity; /* in indices (u32); a command that would not fit raises MIP_ERR_CAPACITY */
+  /* Optional (needs MIP_OUT_DEVICE): N x VkAccelerationStructureInstanceKHR (64 B), one per
+   * instance in draw_index order, as build_acceleration_structures fills them
+   * (src/renderer/systems/acceleration_strucures.rs:419-451): transform = rows 0..2 of the model
+   * matrix (row-major 3x4), instanceCustomIndex = draw_index, mask = 0xFF, sbt offset 0,
+   * flags = TRIANGLE_FACING_CULL_DISABLE, accelerationStructureReference = the mesh's BLAS
+   * address (mip_set_blas_addresses; 0 if never set). */
+  void* tlas_instances;
 } MipOutputs;
 
 typedef struct MipTimings {
@@ -189,6 +196,11 @@ int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* ro
  * not validated — the caller guarantees id < m). */
 int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw,
                                  const void* scale, const void* mesh_id, uint32_t n);
+
+/* Per-mesh bottom-level acceleration structure device addresses for MipOutputs.tlas_instances
+ * (vkGetAccelerationStructureDeviceAddressKHR per GltfMesh, acceleration_strucures.rs:430-437).
+ * m must equal the mesh table's size. Host pointer; copied. */
+int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint32_t m);
 
 /* Upload the consolidated geometry the per-triangle stage reads (ConsolidatedMeshBuffers'
  * position_buffer and index_buffer, consolidate_mesh_buffers.rs): packed vec3 positions and

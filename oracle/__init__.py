@@ -18,4 +18,5 @@ from .oracle import (  # noqa: F401
     merge_draw_lists,
     camera_pv,
     cull_all_triangles,
+    tlas_instances,
 )

@@ -576,3 +576,22 @@ uint32_t orc_cull_all_triangles(OrcDrawCmd* cmds, uint32_t count, const uint32_t
   /* compact_draw_stream.comp runs after generate_work: commands whose triangles all died vanish */
   return orc_compact_draw_stream(cmds, count, cmds);
 }
+
+/* src/renderer/systems/acceleration_strucures.rs:419-451 */
+void orc_tlas_instances(uint32_t n, const float* model, const uint32_t* mesh_id, const uint64_t* blas_address,
+                        uint32_t first_instance_base, void* out) {
+  unsigned char* o = (unsigned char*)out;
+  for (uint32_t i = 0; i < n; ++i, o += 64) {
+    const float* m = &model[(size_t)i * 16];
+    float transform[12];
+    for (int r = 0; r < 3; ++r)          /* model_matrix.rows(0, 3).transpose().as_slice(): row-major 3x4 */
+      for (int c = 0; c < 4; ++c) transform[r * 4 + c] = m[c * 4 + r];
+    const uint32_t custom_and_mask = ((first_instance_base + i) & 0xffffffu) | (0xFFu << 24); /* Packed24_8::new(draw_index, 0xFF) */
+    const uint32_t sbt_and_flags = 0u | (0x1u << 24); /* TRIANGLE_FACING_CULL_DISABLE = 1 */
+    const uint64_t blas = blas_address ? blas_address[mesh_id[i]] : 0;
+    memcpy(o, transform, 48);
+    memcpy(o + 48, &custom_and_mask, 4);
+    memcpy(o + 52, &sbt_and_flags, 4);
+    memcpy(o + 56, &blas, 8);
+  }
+}

@@ -159,6 +159,12 @@ uint32_t orc_cull_all_triangles(OrcDrawCmd* cmds, uint32_t count, const uint32_t
 void orc_src_index_offsets(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id, const uint8_t* coarse_culled,
                            const OrcMesh* meshes, const float cam_pos[3], uint32_t* out);
 
+/* ---- row f-4: TLAS instance rows (src/renderer/systems/acceleration_strucures.rs:419-451) ----
+ * out: n x 64 bytes = VkAccelerationStructureInstanceKHR { float transform[12] (rows 0..2 of the
+ * model matrix, row-major), u32 custom_index:24|mask:8, u32 sbt_offset:24|flags:8, u64 blas }. */
+void orc_tlas_instances(uint32_t n, const float* model, const uint32_t* mesh_id, const uint64_t* blas_address,
+                        uint32_t first_instance_base, void* out);
+
 /* CameraMatrices.pv = projection * view for orc_project_camera's camera (column-major). */
 void orc_camera_pv(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect, float fovy_degrees,
                    float near_z, float far_z, float pv[16]);

@@ -136,6 +136,17 @@ def merge_draw_lists(lists, index_totals):
     return out[:n], int(tot.value)
 
 
+def tlas_instances(model, mesh_id, blas_address=None, first_instance_base=0):
+    model = _f32(model).reshape(-1, 16)
+    n = len(model)
+    mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32)
+    out = np.zeros((n, 16), np.uint32)
+    blas = None if blas_address is None else np.ascontiguousarray(blas_address, dtype=np.uint64)
+    lib().orc_tlas_instances(C.c_uint32(n), _p(model), _p(mesh_id), _p(blas) if blas is not None else None,
+                             C.c_uint32(first_instance_base), _p(out))
+    return out
+
+
 def camera_pv(cam_pos=(0.0, 1.0, 2.0), cam_rot_ijkw=(0.0, 0.0, 0.0, 1.0), aspect=2.0, fovy_degrees=70.0,
               near=0.1, far=100.0):
     pv = np.empty(16, np.float32)

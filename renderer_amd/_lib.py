@@ -26,7 +26,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_set_geometry", "mip_run", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
+    "mip_set_instances_device", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -71,6 +71,7 @@ class MipOutputs(C.Structure):
         ("reserved", C.c_uint32),
         ("culled_index_buffer", C.c_void_p),
         ("culled_index_capacity", C.c_uint64),
+        ("tlas_instances", C.c_void_p),
     ]
 
 
@@ -123,6 +124,8 @@ def load_library():
     lib.mip_set_instances.restype = C.c_int32
     lib.mip_set_instances_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.mip_set_instances_device.restype = C.c_int32
+    lib.mip_set_blas_addresses.argtypes = [vp, vp, C.c_uint32]
+    lib.mip_set_blas_addresses.restype = C.c_int32
     lib.mip_set_geometry.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.mip_set_geometry.restype = C.c_int32
     lib.mip_run.argtypes = [vp, C.c_void_p, C.c_void_p]

@@ -71,6 +71,8 @@ struct KernelArgs {
   uint32_t* index_total;        // optional
   uint32_t* src_index_offset;   // optional: per emitted command, where its LOD's indices start (row f-1)
   float* world_aabb;            // n*6 or null
+  uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
+  const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
@@ -493,12 +495,12 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   }
 
   // ---- stage the matrix rows for the transposed store ----
-  if (a.model) {
+  if (a.model || a.tlas_instances) {
     float4* dst = reinterpret_cast<float4*>(&s_mat[tid * 12]);
     dst[0] = make_float4(inst.m[0], inst.m[1], inst.m[2], inst.m[3]);
     dst[1] = make_float4(inst.m[4], inst.m[5], inst.m[6], inst.m[7]);
     dst[2] = make_float4(inst.m[8], inst.m[9], inst.m[10], inst.m[11]);
-    s_row3[tid] = inst.row3;
+    s_row3[tid] = inst.row3 | (mesh << 4);  // NaN bits of row 3 + the mesh id (for the TLAS rows)
   }
   __syncthreads();
 
@@ -536,11 +538,38 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
       for (uint32_t s4 = 0; s4 < 4; ++s4) {
         const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
         const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
-        const uint32_t bits = s_row3[wave_first + local];
+        const uint32_t bits = s_row3[wave_first + local] & 15u;
         float w = (col == 3u) ? 1.0f : 0.0f;
         if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
         if (tile_first + wave_first + local < a.n)
           out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
+      }
+    }
+
+    // ---- optional TLAS instance rows (acceleration_strucures.rs:419-451), same transposed store ----
+    // VkAccelerationStructureInstanceKHR = { 3x4 row-major transform = rows 0..2 of M,
+    //   instanceCustomIndex:24 = draw_index | mask:8 = 0xFF, sbtOffset:24 = 0 | flags:8 =
+    //   TRIANGLE_FACING_CULL_DISABLE, BLAS device address }, for EVERY instance (visible or not).
+    if (a.tlas_instances) {
+      const uint32_t wave_first = wave * 64u;
+      const float* src = &s_mat[wave_first * 12];
+      uint4* out = a.tlas_instances + ((size_t)tile_first + wave_first) * 4;
+      const uint32_t q = lane & 3u;
+  #pragma unroll
+      for (uint32_t s4 = 0; s4 < 4; ++s4) {
+        const uint32_t local = 16u * s4 + (lane >> 2);
+        const uint32_t draw = tile_first + wave_first + local;
+        uint4 v;
+        if (q < 3u) {  // row q: one element of each staged column
+          const float* col = src + local * 12u + q;
+          v = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[3]), __float_as_uint(col[6]), __float_as_uint(col[9]));
+        } else {
+          const uint32_t mesh_of = s_row3[wave_first + local] >> 4;
+          const unsigned long long blas = (draw < a.n && a.blas_address) ? a.blas_address[mesh_of] : 0ull;
+          v = make_uint4(((a.first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
+                         (uint32_t)blas, (uint32_t)(blas >> 32));
+        }
+        if (draw < a.n) out[64u * s4 + lane] = v;
       }
     }
 

@@ -48,6 +48,7 @@ struct MipContext {
   uint32_t* d_mesh_id = nullptr;
   mip::MeshEntry* d_meshes = nullptr;
   mip::MeshDraw* d_mesh_draw = nullptr;
+  unsigned long long* d_blas = nullptr;  // per-mesh BLAS device addresses (optional, row f-4)
   // consolidated geometry for the per-triangle stage (row f-1)
   float* d_vertices = nullptr;
   uint32_t* d_indices = nullptr;
@@ -145,6 +146,7 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
   (void)hipFree(ctx->d_mesh_draw);
+  (void)hipFree(ctx->d_blas);
   (void)hipFree(ctx->d_vertices);
   (void)hipFree(ctx->d_indices);
   for (auto& sl : ctx->slots) {
@@ -282,6 +284,17 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   return MIP_OK;
 }
 
+int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint32_t m) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!addresses && m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "addresses is NULL");
+  if (!ctx->have_meshes || m != ctx->m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u addresses for %u meshes", m, ctx->m);
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  if (!ctx->d_blas) MIP_HIP(ctx, hipMalloc(&ctx->d_blas, (size_t)(ctx->max_meshes ? ctx->max_meshes : 1) * 8));
+  if (m) MIP_HIP(ctx, hipMemcpy(ctx->d_blas, addresses, (size_t)m * 8, hipMemcpyHostToDevice));
+  return MIP_OK;
+}
+
 int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_vertices, const uint32_t* indices,
                          uint32_t n_indices) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
@@ -381,6 +394,11 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : sl.d_scalars + 0) : nullptr;
   a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : sl.d_scalars + 1) : nullptr;
   a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
+  if (out->tlas_instances) {
+    if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "tlas_instances needs MIP_OUT_DEVICE");
+    a.tlas_instances = (uint4*)out->tlas_instances;
+    a.blas_address = ctx->d_blas;
+  }
   if (triangles) {
     // the instance kernel emits into the slot's scratch list; the triangle stage rewrites
     // indexCount there and the final compaction lands in the caller's buffers

@@ -110,6 +110,10 @@ class InstancePipeline:
         i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self._check(self._lib.mip_set_geometry(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)))
 
+    def set_blas_addresses(self, addresses):
+        a = np.ascontiguousarray(addresses, dtype=np.uint64).reshape(-1)
+        self._check(self._lib.mip_set_blas_addresses(self._ctx, a.ctypes.data, len(a)))
+
     def set_instances_device(self, pos_ptr, rot_ptr, scale_ptr, mesh_id_ptr, n):
         self._check(self._lib.mip_set_instances_device(self._ctx, pos_ptr, rot_ptr, scale_ptr,
                                                        mesh_id_ptr, int(n)))
@@ -149,7 +153,8 @@ class InstancePipeline:
         return res
 
     def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0,
-                   draw_index_total=0, world_aabb=0, async_=False, culled_index_buffer=0, culled_index_capacity=0):
+                   draw_index_total=0, world_aabb=0, async_=False, culled_index_buffer=0, culled_index_capacity=0,
+                   tlas_instances=0):
         """Device pointers in, nothing copied. `frame` from make_frame()."""
         out = MipOutputs()
         out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
@@ -161,6 +166,7 @@ class InstancePipeline:
         out.world_aabb = world_aabb or None
         out.culled_index_buffer = culled_index_buffer or None
         out.culled_index_capacity = int(culled_index_capacity)
+        out.tlas_instances = tlas_instances or None
         self._check(self._lib.mip_run(self._ctx, C.byref(frame), C.byref(out)))
 
     def prepare_outputs(self, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0, draw_index_total=0,

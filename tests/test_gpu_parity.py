@@ -375,3 +375,35 @@ def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):
             assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
     with pytest.raises(ra.MipError):
         ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=99)
+
+
+def test_tlas_instance_rows(ra, oracle_mod):
+    """Row f-4: VkAccelerationStructureInstanceKHR rows for every instance, with and without the
+    matrix output, with BLAS addresses and a draw_index base."""
+    import torch
+
+    from helpers import same_floats
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=10_001)
+    s["pos"][17, 1] = np.nan
+    blas = (np.arange(len(s["meshes"]), dtype=np.uint64) << np.uint64(20)) + np.uint64(0xABC0000000)
+    dev = torch.device("cuda", 0)
+    want_run = run_oracle(oracle_mod, s)
+    want = oracle_mod.tlas_instances(want_run["model"], s["mesh_id"], blas, first_instance_base=5)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_blas_addresses(blas)
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=5)
+        for with_model in (True, False):
+            tlas = torch.zeros((s["n"], 16), dtype=torch.int32, device=dev)
+            model = torch.zeros((s["n"], 16), dtype=torch.float32, device=dev)
+            p.run_device(frame, model=model.data_ptr() if with_model else 0, tlas_instances=tlas.data_ptr())
+            got = tlas.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[:, 12:], want[:, 12:])                       # index|mask, sbt|flags, BLAS address
+            assert same_floats(got[:, :12].view(np.float32), want[:, :12].view(np.float32))
+            if with_model:
+                assert same_floats(model.cpu().numpy(), want_run["model"])
+        with pytest.raises(ra.MipError):
+            p.set_blas_addresses(blas[:3])
