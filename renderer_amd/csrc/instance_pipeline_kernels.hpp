@@ -719,6 +719,7 @@ struct TriangleArgs {
   unsigned long long capacity;    // in indices
   uint32_t first_instance_base;
   uint32_t* error_flag;
+  uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
   float pv[16];
 };
 
@@ -729,20 +730,28 @@ __device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x
   for (int r = 0; r < 4; ++r) o[r] = m[0 * 4 + r] * x + m[1 * 4 + r] * y + m[2 * 4 + r] * z + m[3 * 4 + r] * w;
 }
 
-__global__ __launch_bounds__(256) void mip_triangle_cull_kernel(const TriangleArgs a) {
+#ifndef MIP_TRI_MIN_WAVES_PER_SIMD
+#define MIP_TRI_MIN_WAVES_PER_SIMD 4
+#endif
+
+__global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  // readfirstlane makes the command index provably wave-uniform: the command words and the
-  // model matrix are then scalar loads held in SGPRs
-  const uint32_t wave_global = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)));
-  const uint32_t wave_stride = gridDim.x * waves_per_block;
   const uint32_t count = *a.count;
   float pv[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
 
-  for (uint32_t c = wave_global; c < count; c += wave_stride) {
-    // the command and its model matrix are wave-uniform
+  // Commands differ 1000x in triangle count (LODs, mixed meshes): waves pull the next command
+  // from a ticket counter instead of striding over the list (measured: static striding left a
+  // third of the waves idle at 5 k commands). The counter is zeroed by the host per launch.
+  // Every lane takes part in the add (lane 0 adds 1, the others 0: the compiler folds the wave's
+  // adds into one atomic), so there is no divergent branch around it, and the loop is bounded
+  // by the command count whatever the counter holds.
+  for (uint32_t pulled = 0; pulled <= count; ++pulled) {
+    const uint32_t old = atomicAdd(a.ticket, lane == 0u ? 1u : 0u);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);  // wave-uniform: scalar loads below
+    if (c >= count) break;
+
     const uint32_t index_count = a.cmds[c * kCmdWords + 0];
     const uint32_t first_index = a.cmds[c * kCmdWords + 2];
     const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
@@ -758,13 +767,23 @@ __global__ __launch_bounds__(256) void mip_triangle_cull_kernel(const TriangleAr
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
     if (!fits && lane == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const size_t dst_tri = (size_t)first_index / 3u;
+    const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
     uint32_t survivors = 0;
 
+    // software pipeline: the index triple of step k+1 is in flight while step k gathers and tests
+    uint32_t n0 = 0, n1 = 0, n2 = 0;
+    if (lane < n_tris) {
+      const uint32_t* ip = tri_indices + (size_t)lane * 3;
+      n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+    }
     for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
       const uint32_t t = t0 + lane;
       const bool valid = t < n_tris;
-      const uint32_t* ip = a.indices + (size_t)(src_tri + (valid ? t : 0u)) * 3;
-      const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+      const uint32_t i0 = n0, i1 = n1, i2 = n2;
+      if (t + 64u < n_tris) {
+        const uint32_t* ip = tri_indices + (size_t)(t + 64u) * 3;
+        n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+      }
       const uint32_t ix[3] = {i0, i1, i2};
       float clip[3][4];
 #pragma unroll

@@ -32,7 +32,7 @@ struct MipContext {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     unsigned long long* d_status = nullptr;  // level-0 granules, accumulators, group starts
-    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count
+    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t epoch = 0;
@@ -460,6 +460,8 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
       t.capacity = out->culled_index_capacity;
       t.first_instance_base = frame->first_instance_base;
       t.error_flag = ctx->d_error;
+      t.ticket = sl.d_scalars + 3;
+      MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
       // one wave per command; the command count lives on the device, so size for the worst case
       uint32_t blocks = (n + 3u) / 4u;
