@@ -60,16 +60,24 @@ class DeviceOutputs:
                     draw_index_total=self.scalars.data_ptr() + 4)
 
 
-def time_steps(torch, dist, step, steps, warmup, distributed):
-    for _ in range(warmup):
-        step()
+def time_steps(torch, dist, step, steps, warmup, distributed, issue_many=None):
+    """issue_many(k), if given, enqueues k steps from compiled code (mip_run_many) instead of k
+    Python-level calls of step()."""
+    if issue_many is not None:
+        issue_many(warmup)
+    else:
+        for _ in range(warmup):
+            step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    if issue_many is not None:
+        issue_many(steps)
+    else:
+        for _ in range(steps):
+            step()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -287,7 +295,13 @@ def main():
             k = counter[0]
             counter[0] = (k + 1) % frames
             pipe.run_prepared(fref, prepared[k])
+
+        def issue_many(k):
+            if k:
+                pipe.run_many(frame, prepared, k)
     else:
+        issue_many = None
+
         def step():
             exchange.step(frame, outs)
 
@@ -304,7 +318,7 @@ def main():
     visible = int(np.unpackbits(bitmap.view(np.uint8)).sum())
     v_emit = count / max(n_local, 1)
 
-    dt = time_steps(torch, dist, step, args.steps, args.warmup, distributed)
+    dt = time_steps(torch, dist, step, args.steps, args.warmup, distributed, issue_many=issue_many)
     pipe.wait()
     ms_per_step = dt / args.steps * 1e3
     value = n_global * args.steps / dt
@@ -331,6 +345,7 @@ def main():
             "emitted_fraction": v_emit,
             "draw_list_exchange": "rccl all-gather + merge" if exchange is not None else "none (< 1 M instances or 1 GPU)",
             "frames_in_flight": frames,
+            "host_loop": "compiled (mip_run_many)" if exchange is None else "python",
             "outputs": "model[N] mat4 + visibility bitmap + compacted VkDrawIndexedIndirectCommand stream, HBM-resident",
         },
     }

@@ -214,6 +214,13 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
  * MIP_OUT_ASYNC. */
 int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out);
 
+/* Enqueue `steps` frames back to back from compiled code: frame k uses outputs[k % n_outputs]
+ * (give at least frames_in_flight output sets). Every output set must carry
+ * MIP_OUT_DEVICE | MIP_OUT_ASYNC. Equivalent to calling mip_run `steps` times; exists so that a
+ * host in a scripting language does not pay its per-call overhead per frame. */
+int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
+                     uint32_t steps);
+
 /* Block until everything enqueued by this context has finished; reports a
  * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
 int32_t mip_wait(MipContext* ctx);

@@ -515,6 +515,17 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   return check_device_error(ctx);
 }
 
+int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs, uint32_t steps) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!frame || !outputs || n_outputs == 0) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/outputs is NULL or empty");
+  for (uint32_t k = 0; k < n_outputs; ++k)
+    if ((outputs[k].flags & (MIP_OUT_DEVICE | MIP_OUT_ASYNC)) != (MIP_OUT_DEVICE | MIP_OUT_ASYNC))
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_many needs MIP_OUT_DEVICE | MIP_OUT_ASYNC outputs");
+  for (uint32_t k = 0; k < steps; ++k)
+    if (int32_t rc = mip_run(ctx, frame, &outputs[k % n_outputs])) return rc;
+  return MIP_OK;
+}
+
 int32_t mip_wait(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;

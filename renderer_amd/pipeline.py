@@ -197,6 +197,15 @@ class InstancePipeline:
         if rc != 0:
             self._check(rc)
 
+    def run_many(self, frame, prepared_outputs, steps):
+        """`steps` frames issued from compiled code, rotating over the prepared output sets."""
+        arr = (MipOutputs * len(prepared_outputs))()
+        for k, o in enumerate(prepared_outputs):
+            C.memmove(C.addressof(arr[k]), C.addressof(o), C.sizeof(MipOutputs))
+        rc = self._lib.mip_run_many(self._ctx, C.addressof(frame), C.addressof(arr), len(prepared_outputs), int(steps))
+        if rc != 0:
+            self._check(rc)
+
     def wait(self):
         self._check(self._lib.mip_wait(self._ctx))
 
