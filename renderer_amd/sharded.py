@@ -96,6 +96,40 @@ class DrawListExchange:
         return cmds.copy(), total, index_total
 
 
+class PipelinedExchange:
+    """F frames in flight on the sharded path: F contexts, each bound to its own torch stream
+    (kernel -> all-gather -> merge stay ordered within a frame), issued round-robin so that
+    frame k+1's kernel runs while frame k's draw lists are still on the wire."""
+
+    def __init__(self, make_pipe, n_local, world, rank, device, frames=2, dist=None, torch=None, group=None):
+        if torch is None:
+            import torch
+        self.torch = torch
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(frames)]
+        self.pipes = [make_pipe(st.cuda_stream) for st in self.streams]
+        self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group)
+                          for p in self.pipes]
+        self.next = 0
+
+    def step(self, frame, outs_per_frame):
+        k = self.next
+        self.next = (k + 1) % len(self.exchanges)
+        with self.torch.cuda.stream(self.streams[k]):
+            self.exchanges[k].step(frame, outs_per_frame[k])
+        return k
+
+    def wait(self):
+        for p in self.pipes:
+            p.wait()
+
+    def tighten(self, margin=1.0625):
+        return [ex.tighten(margin) for ex in self.exchanges]
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+
+
 def make_shard_frame(planes, cam_pos, n_global, world, rank):
     lo, _ = shard_range(n_global, world, rank)
     return make_frame(planes, cam_pos, first_instance_base=lo)

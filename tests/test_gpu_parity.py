@@ -407,3 +407,64 @@ def test_tlas_instance_rows(ra, oracle_mod):
                 assert same_floats(model.cpu().numpy(), want_run["model"])
         with pytest.raises(ra.MipError):
             p.set_blas_addresses(blas[:3])
+
+
+def test_run_many_and_pipelined_exchange(ra, oracle_mod):
+    """mip_run_many (frames issued from compiled code) and two sharded frames in flight (world 1)."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from renderer_amd.pipeline import make_frame
+    from renderer_amd.sharded import PipelinedExchange, make_shard_frame
+
+    s = ra.scene.make_scene(3, n=120_000)
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+    dev = torch.device("cuda", 0)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in range(2):
+            cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                                                        draw_index_total=scal.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        p.run_many(make_frame(s["planes"], s["cam_pos"]), [x[2] for x in sets], 25)
+        p.wait()
+        for cmds, scal, _ in sets:
+            count = int(scal[0].item())
+            assert count == want["draw_count"]
+            got = cmds[:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+            assert got.tobytes() == want["draw_cmds"].tobytes()
+        with pytest.raises(ra.MipError):  # host-pointer outputs are not accepted by run_many
+            p.run_many(make_frame(s["planes"], s["cam_pos"]), [p.prepare_outputs(async_=False)], 1)
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29583")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        def make_pipe(stream_handle):
+            q = ra.InstancePipeline(max_instances=s["n"], max_meshes=64, stream=stream_handle)
+            q.set_mesh_table(s["meshes"])
+            q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            return q
+
+        px = PipelinedExchange(make_pipe, s["n"], 1, 0, dev, frames=2)
+        frame = make_shard_frame(s["planes"], s["cam_pos"], s["n"], 1, 0)
+        torch.cuda.synchronize()
+        for _ in range(6):
+            px.step(frame, [None, None])
+        px.wait()
+        px.tighten()
+        for _ in range(4):
+            px.step(frame, [None, None])
+        px.wait()
+        for ex in px.exchanges:
+            cmds, total, index_total = ex.merged_draw_list()
+            assert total == want["draw_count"] and cmds.tobytes() == want["draw_cmds"].tobytes()
+        px.close()
+    finally:
+        dist.destroy_process_group()
