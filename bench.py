@@ -205,8 +205,8 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
         "instances": n, "commands_in": count0, "commands_out": count1, "triangles_in": tris_in,
         "triangles_surviving": tris_out, "ms_per_frame": dt * 1e3, "triangles_per_s": tris_in / dt,
         "index_stream_write_GBps": tris_out * 12 / dt / 1e9,
-        "note": "VALU-bound (two mat4*vec4 per vertex without FMA + 6 correctly rounded divides per triangle); "
-                "geometry is L2-resident, HBM traffic is the 12 B per surviving triangle",
+        "note": "instruction-issue/latency bound, not HBM: two mat4*vec4 per vertex without FMA + 6 correctly rounded "
+                "divides per triangle; geometry is L2-resident, HBM traffic is the 12 B per surviving triangle",
     }
     if with_cpu:
         import oracle
