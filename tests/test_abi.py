@@ -119,3 +119,18 @@ def test_scene_generator_is_deterministic_and_shardable():
     assert [int(v) for v in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
     norms = np.linalg.norm(a["rot"].astype(np.float64), axis=1)
     assert np.allclose(norms, 1.0, atol=1e-6)
+
+
+def test_rust_binding_sizes_and_symbols_follow_the_header():
+    """integration/rust/mip-sys/src/lib.rs cannot be compiled here; keep its layout guards and its
+    extern block in step with the C header mechanically."""
+    from renderer_amd import _lib
+
+    text = open(os.path.join(ROOT, "integration", "rust", "mip-sys", "src", "lib.rs")).read()
+    guards = dict(re.findall(r"size_of::<(\w+)>\(\) == (\d+)", text))
+    want = {"MipConfig": C.sizeof(_lib.MipConfig), "MipMesh": 80, "MipFrame": C.sizeof(_lib.MipFrame),
+            "MipOutputs": C.sizeof(_lib.MipOutputs), "MipDrawIndexedIndirectCommand": 20}
+    assert {k: int(v) for k, v in guards.items()} == want
+    rust_fns = set(re.findall(r"pub fn (mip_[a-z_]+)\(", text))
+    assert rust_fns <= set(_declared_functions())
+    assert {"mip_create", "mip_run", "mip_run_many", "mip_set_geometry", "mip_merge_draw_lists"} <= rust_fns
