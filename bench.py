@@ -263,6 +263,10 @@ def main():
     if distributed:
         dist.init_process_group("nccl", device_id=device)
 
+    if not os.path.exists(renderer_amd.library_path()):  # bare checkout: build the HIP library first
+        import __graft_entry__
+
+        __graft_entry__.build()
     renderer_amd.load_library()
     cfg = scene.CONFIGS[args.config]
     n_local = args.instances if args.instances is not None else cfg["n"]

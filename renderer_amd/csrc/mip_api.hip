@@ -236,6 +236,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
+    if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
+      for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
     MIP_HIP(ctx, hipEventCreate(&ctx->ev1));
     return MIP_OK;

@@ -468,3 +468,31 @@ def test_run_many_and_pipelined_exchange(ra, oracle_mod):
         px.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_epoch_tag_wrap_clears_the_prefix_state(ra, oracle_mod):
+    """The 23-bit launch tag wraps after 8 388 606 launches per frame slot; the host then clears the
+    prefix state and restarts at 1. Start two launches before the wrap and cross it."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+os.environ["MIP_TEST_EPOCH_START"] = str((1 << 23) - 1 - 3)
+import numpy as np, renderer_amd, oracle
+from renderer_amd import scene
+s = scene.make_scene(3, n=70_000)
+want = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=4, want=("draw_cmds",))
+for frames in (1, 2):
+    with renderer_amd.InstancePipeline(s["n"], 64, frames_in_flight=frames) as p:
+        p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        for k in range(12):
+            got = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))
+            assert got["draw_count"] == want["draw_count"] and got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes(), (frames, k)
+print("WRAP_OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "WRAP_OK" in out.stdout, out.stderr[-2000:]
