@@ -496,3 +496,28 @@ print("WRAP_OK")
 '''
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "WRAP_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_device_resident_upload_and_timings(ra, oracle_mod):
+    """mip_set_instances_device (columns already in HBM) and the hipEvent timing counters."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=50_000)
+    dev = torch.device("cuda", 0)
+    cols = [torch.from_numpy(np.ascontiguousarray(s[k])).to(dev) for k in ("pos", "rot", "scale")]
+    mesh = torch.from_numpy(s["mesh_id"].astype(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, timing=True) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), mesh.data_ptr(), s["n"])
+        got = p.run_host(s["planes"], s["cam_pos"])
+        assert_parity(got, run_oracle(oracle_mod, s, threads=8), "device upload")
+        model = torch.empty((s["n"], 16), dtype=torch.float32, device=dev)
+        for _ in range(5):
+            p.run_device(make_frame(s["planes"], s["cam_pos"]), model=model.data_ptr())
+        t = p.timings()
+        assert t["runs"] == 6 and 0 < t["last_kernel_ms"] < 5 and t["total_kernel_ms"] >= t["last_kernel_ms"]
+        p.reset_timings()
+        assert p.timings()["runs"] == 0
