@@ -314,7 +314,7 @@ __device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&p
 // No payload is handed off behind these words (every tile writes its own commands), so no
 // release/acquire fence is involved; readers use relaxed agent-scope atomic loads (sc1).
 
-constexpr uint32_t kAccCountBits = 20, kAccArrivalBits = 12;
+constexpr uint32_t kAccCountBits = 20;  // the 12 bits above it count the tiles that have added
 // Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
 // words would put all of that traffic (and the atomics) on one or two memory channels.
 constexpr uint32_t kAccStrideWords = 32;

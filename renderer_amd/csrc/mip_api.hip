@@ -55,12 +55,10 @@ struct MipContext {
   uint32_t n_vertices = 0, n_indices = 0;
   bool have_geometry = false;
   int cu_count = 0;
-  // look-back state
+  // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
-  uint32_t epoch = 0;
-  bool status_dirty = false;
-  uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU  // instance count changed: clear the prefix state before the next launch
+  uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   // staging for MIP_OUT_HOST
