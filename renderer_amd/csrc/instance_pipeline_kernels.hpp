@@ -6,9 +6,12 @@
 //   loads   : pos (12 B) + quat (16 B) + scale (4 B) + mesh id (4 B)            = 36 B
 //   compute : M = T·R·S, 8-corner world AABB, 6-plane test, LOD pick             (VALU, no FMA)
 //   stores  : mat4 through an LDS transpose so every store instruction writes
-//             1 KiB contiguous (64 B), 1 visibility bit, and — after a decoupled
-//             look-back over per-tile {count, Σ index_len} granules — the tile's
-//             surviving VkDrawIndexedIndirectCommands, coalesced, in draw_index order.
+//             1 KiB contiguous (64 B), 1 visibility bit, and — after a one-hop look-up of
+//             the tile's exclusive prefix over per-tile granules and per-group atomic
+//             accumulators of {count, Σ index_len} — the tile's surviving
+//             VkDrawIndexedIndirectCommands, coalesced, in draw_index order.
+//   also here: the shard-merge kernel (multi-GPU), the per-triangle cull kernel (row f-1)
+//             and the command re-compaction that follows it.
 //
 // Reference semantics (paths in farnoy/renderer):
 //   src/ecs.rs:52-64 model_matrix_calculation, :138-181 aabb_calculation,
