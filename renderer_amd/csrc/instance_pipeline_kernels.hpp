@@ -37,7 +37,10 @@ namespace mip {
 #define MIP_MIN_WAVES_PER_SIMD 6
 #endif
 
-constexpr uint32_t kTile = 256;           // instances per tile == threads per workgroup
+#ifndef MIP_TILE
+#define MIP_TILE 256
+#endif
+constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
@@ -321,7 +324,8 @@ constexpr uint32_t kAccCountBits = 20;  // the 12 bits above it count the tiles 
 // Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
 // words would put all of that traffic (and the atomics) on one or two memory channels.
 constexpr uint32_t kAccStrideWords = 32;
-constexpr uint32_t kTagBits = 23, kTileCountBits = 9;
+constexpr uint32_t kTileCountBits = kTile <= 256 ? 9 : (kTile <= 512 ? 10 : 11);
+constexpr uint32_t kTagBits = 32 - kTileCountBits;
 constexpr uint32_t kMaxEpoch = (1u << kTagBits) - 1u;
 static_assert(kTile < (1u << kTileCountBits), "tile count must fit its field");
 
