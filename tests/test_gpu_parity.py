@@ -521,3 +521,18 @@ def test_device_resident_upload_and_timings(ra, oracle_mod):
         assert t["runs"] == 6 and 0 < t["last_kernel_ms"] < 5 and t["total_kernel_ms"] >= t["last_kernel_ms"]
         p.reset_timings()
         assert p.timings()["runs"] == 0
+
+
+def test_gpu_against_float64_formulas(ra):
+    """The north star's own criterion, without the oracle: matrices within 1e-5 relative of a float64
+    evaluation; visibility identical wherever the float64 margin is not within rounding of zero."""
+    import float64_reference as f64
+
+    s = ra.scene.make_scene(3, n=200_000)
+    got = run_gpu(ra, s, want=("model", "visible_bitmap"))
+    b = f64.run(s)
+    denom = np.maximum(np.abs(b["model"]), 1e-3 * np.abs(b["model"]).max(axis=1, keepdims=True))
+    assert np.max(np.abs(got["model"].astype(np.float64) - b["model"]) / denom) < 1e-5  # relative tolerance 1e-5
+    vis = np.unpackbits(got["visible_bitmap"].view(np.uint8), bitorder="little")[: s["n"]].astype(bool)
+    d = b["decided"]
+    assert np.array_equal(~vis[d], b["culled"][d]) and d.mean() > 0.99

@@ -207,3 +207,23 @@ def test_mesh_id_out_of_range_is_rejected(oracle_mod):
     s["mesh_id"][3] = 9
     with pytest.raises(ValueError):
         oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])
+
+
+def test_oracle_against_float64_formulas(oracle_mod):
+    """Independent of operation order: the oracle's matrices are within 1e-5 relative of the float64
+    formulas (the north star's tolerance) and its visibility equals the float64 decision for every
+    instance that is not within rounding distance of a plane."""
+    import float64_reference as f64
+    from renderer_amd import scene
+
+    for config, n in ((2, 30_000), (3, 30_000)):
+        s = scene.make_scene(config, n=n)
+        a = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])
+        b = f64.run(s)
+        denom = np.maximum(np.abs(b["model"]), 1e-3 * np.abs(b["model"]).max(axis=1, keepdims=True))
+        assert np.max(np.abs(a["model"].astype(np.float64) - b["model"]) / denom) < 1e-5
+        assert np.allclose(a["world_aabb"][:, :3], b["mins"], rtol=1e-5, atol=1e-4)
+        assert np.allclose(a["world_aabb"][:, 3:], b["maxs"], rtol=1e-5, atol=1e-4)
+        d = b["decided"]
+        assert d.mean() > 0.99
+        assert np.array_equal(a["coarse_culled"].astype(bool)[d], b["culled"][d])
