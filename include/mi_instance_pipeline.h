@@ -192,6 +192,13 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m);
 int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* rot_ijkw,
                           const float* scale, const uint32_t* mesh_id, uint32_t n);
 
+/* Overwrite a range [first, first + count) of the resident columns (moving entities: the
+ * Changed<Position|Rotation|Scale> filter of a bevy query). A NULL column is left as it is.
+ * The instance count does not change; first + count must not exceed it. Host pointers; copied
+ * after everything in flight has drained. */
+int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, const float* pos_xyz,
+                             const float* rot_ijkw, const float* scale, const uint32_t* mesh_id);
+
 /* Same, from DEVICE pointers of the context's GPU (device-to-device copies; mesh ids are
  * not validated — the caller guarantees id < m). */
 int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw,

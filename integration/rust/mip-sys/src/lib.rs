@@ -83,6 +83,8 @@ extern "C" {
     pub fn mip_set_mesh_table(ctx: *mut MipContext, meshes: *const MipMesh, m: u32) -> i32;
     pub fn mip_set_instances(ctx: *mut MipContext, pos_xyz: *const f32, rot_ijkw: *const f32, scale: *const f32,
                              mesh_id: *const u32, n: u32) -> i32;
+    pub fn mip_update_instances(ctx: *mut MipContext, first: u32, count: u32, pos_xyz: *const f32, rot_ijkw: *const f32,
+                                scale: *const f32, mesh_id: *const u32) -> i32;
     pub fn mip_set_geometry(ctx: *mut MipContext, vertex_xyz: *const f32, n_vertices: u32, indices: *const u32,
                             n_indices: u32) -> i32;
     pub fn mip_set_blas_addresses(ctx: *mut MipContext, addresses: *const u64, m: u32) -> i32;

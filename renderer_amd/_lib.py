@@ -26,7 +26,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -124,6 +124,8 @@ def load_library():
     lib.mip_set_instances.restype = C.c_int32
     lib.mip_set_instances_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     lib.mip_set_instances_device.restype = C.c_int32
+    lib.mip_update_instances.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    lib.mip_update_instances.restype = C.c_int32
     lib.mip_set_blas_addresses.argtypes = [vp, vp, C.c_uint32]
     lib.mip_set_blas_addresses.restype = C.c_int32
     lib.mip_set_geometry.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]

@@ -347,6 +347,26 @@ int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* ro
   return set_instances_common(ctx, pos_xyz, rot_ijkw, scale, mesh_id, n, hipMemcpyHostToDevice);
 }
 
+int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, const float* pos_xyz, const float* rot_ijkw,
+                             const float* scale, const uint32_t* mesh_id) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->have_instances) return fail(ctx, MIP_ERR_NOT_READY, "no resident instances to update");
+  if ((uint64_t)first + count > ctx->n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "range [%u, %u) exceeds %u instances", first, first + count, ctx->n);
+  if (mesh_id)
+    for (uint32_t i = 0; i < count; ++i)
+      if (mesh_id[i] >= ctx->m)
+        return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "instance %u: mesh id %u >= %u meshes", first + i, mesh_id[i], ctx->m);
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  if (count) {
+    if (pos_xyz) MIP_HIP(ctx, hipMemcpy(ctx->d_pos + (size_t)first * 3, pos_xyz, (size_t)count * 12, hipMemcpyHostToDevice));
+    if (rot_ijkw) MIP_HIP(ctx, hipMemcpy(ctx->d_rot + first, rot_ijkw, (size_t)count * 16, hipMemcpyHostToDevice));
+    if (scale) MIP_HIP(ctx, hipMemcpy(ctx->d_scale + first, scale, (size_t)count * 4, hipMemcpyHostToDevice));
+    if (mesh_id) MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id + first, mesh_id, (size_t)count * 4, hipMemcpyHostToDevice));
+  }
+  return MIP_OK;
+}
+
 int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw, const void* scale,
                                  const void* mesh_id, uint32_t n) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;

@@ -110,6 +110,21 @@ class InstancePipeline:
         i = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
         self._check(self._lib.mip_set_geometry(self._ctx, v.ctypes.data, len(v), i.ctypes.data, len(i)))
 
+    def update_instances(self, first, pos_xyz=None, rot_ijkw=None, scale=None, mesh_id=None):
+        """Overwrite a range of the resident columns (None = keep)."""
+        cols, count = [], None
+        for arr, dtype, width in ((pos_xyz, np.float32, 3), (rot_ijkw, np.float32, 4), (scale, np.float32, 1), (mesh_id, np.uint32, 1)):
+            if arr is None:
+                cols.append(None)
+                continue
+            a = np.ascontiguousarray(arr, dtype=dtype).reshape(-1, width)
+            if count is not None and len(a) != count:
+                raise ValueError("columns differ in length")
+            count = len(a)
+            cols.append(a)
+        ptrs = [c.ctypes.data if c is not None else None for c in cols]
+        self._check(self._lib.mip_update_instances(self._ctx, int(first), int(count or 0), *ptrs))
+
     def set_blas_addresses(self, addresses):
         a = np.ascontiguousarray(addresses, dtype=np.uint64).reshape(-1)
         self._check(self._lib.mip_set_blas_addresses(self._ctx, a.ctypes.data, len(a)))

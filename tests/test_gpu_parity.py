@@ -536,3 +536,29 @@ def test_gpu_against_float64_formulas(ra):
     vis = np.unpackbits(got["visible_bitmap"].view(np.uint8), bitorder="little")[: s["n"]].astype(bool)
     d = b["decided"]
     assert np.array_equal(~vis[d], b["culled"][d]) and d.mean() > 0.99
+
+
+def test_partial_instance_updates(ra, oracle_mod):
+    """Moving entities: overwrite ranges of single columns between frames."""
+    s = ra.scene.make_scene(3, n=10_000)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        rng = np.random.default_rng(5)
+        for step in range(4):
+            first = int(rng.integers(0, 9000))
+            count = int(rng.integers(0, 1000))
+            new_pos = rng.normal(0, 20, (count, 3)).astype(np.float32)
+            s["pos"][first : first + count] = new_pos
+            p.update_instances(first, pos_xyz=new_pos)
+            if step % 2:
+                new_scale = rng.uniform(0.1, 3, count).astype(np.float32)
+                new_mesh = rng.integers(0, 64, count).astype(np.uint32)
+                s["scale"][first : first + count] = new_scale
+                s["mesh_id"][first : first + count] = new_mesh
+                p.update_instances(first, scale=new_scale, mesh_id=new_mesh)
+            assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), f"update {step}")
+        with pytest.raises(ra.MipError):
+            p.update_instances(9_990, pos_xyz=np.zeros((20, 3), np.float32))
+        with pytest.raises(ra.MipError):
+            p.update_instances(0, mesh_id=np.array([64], np.uint32))
