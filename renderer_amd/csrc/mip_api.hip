@@ -59,6 +59,7 @@ struct MipContext {
   size_t status_bytes = 0;
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
+  uint32_t tri_block_max = 24576;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   // staging for MIP_OUT_HOST
@@ -234,6 +235,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
+    if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
       for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -483,11 +485,17 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
       t.ticket = sl.d_scalars + 3;
       MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
-      // one wave per command; the command count lives on the device, so size for the worst case
-      uint32_t blocks = (n + 3u) / 4u;
-      const uint32_t max_blocks = (uint32_t)ctx->cu_count * 8u;
-      if (blocks > max_blocks) blocks = max_blocks;
-      hipLaunchKernelGGL(mip::mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, t);
+      // The command count lives on the device; the instance count bounds it. Small frames: one
+      // 1024-thread workgroup per command; large frames: one wave per command (no barriers).
+      if (n <= ctx->tri_block_max) {
+        uint32_t blocks = n < (uint32_t)ctx->cu_count * 2u ? n : (uint32_t)ctx->cu_count * 2u;
+        hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel, dim3(blocks ? blocks : 1u), dim3(mip::kTriBlock), 0, stream, t);
+      } else {
+        uint32_t blocks = (n + 3u) / 4u;
+        const uint32_t max_blocks = (uint32_t)ctx->cu_count * 8u;
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL(mip::mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, t);
+      }
       MIP_HIP(ctx, hipGetLastError());
       mip::RecompactArgs r{};
       r.in_cmds = sl.d_tmp_cmds;
