@@ -8,6 +8,14 @@ from helpers import assert_parity, popcount_bitmap, run_gpu, run_oracle
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 @pytest.fixture(scope="module")
 def ra():
     import renderer_amd
@@ -265,8 +273,8 @@ def test_exchange_step_world_size_one(ra, oracle_mod):
 
     from renderer_amd.sharded import DrawListExchange, make_shard_frame
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29581")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -442,8 +450,8 @@ def test_run_many_and_pipelined_exchange(ra, oracle_mod):
         with pytest.raises(ra.MipError):  # host-pointer outputs are not accepted by run_many
             p.run_many(make_frame(s["planes"], s["cam_pos"]), [p.prepare_outputs(async_=False)], 1)
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29583")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         def make_pipe(stream_handle):
