@@ -242,6 +242,34 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
                              uint64_t chunk_stride_bytes, void* out_cmds, uint32_t* out_count,
                              int32_t async);
 
+/* ---- sharded scenes without a Python host: RCCL straight from the library ------------------
+ * librccl.so.1 is opened with dlopen on first use, so single-GPU hosts do not need it. The
+ * exchange is the one of SURVEY.md §8e: every rank runs its shard, ONE ncclAllGather moves the
+ * fixed-size chunks [MipShardHeader | chunk_capacity x 20 B], mip_merge_draw_lists' kernel
+ * concatenates them. Needs a context with one frame in flight. */
+#define MIP_COMM_ID_BYTES 128u
+
+/* ncclGetUniqueId: call on one rank, hand the 128 bytes to the others by any means. */
+int32_t mip_comm_unique_id(uint8_t out_id[MIP_COMM_ID_BYTES]);
+/* ncclCommInitRank on the context's device: collective over all `world` ranks. */
+int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+int32_t mip_comm_destroy(MipContext* ctx);
+
+typedef struct MipShardedOutputs {
+  void* model;              /* this rank's shard: n_local x mat4, or NULL */
+  uint32_t* visible_bitmap; /* this rank's shard, or NULL */
+  void* world_aabb;         /* this rank's shard, or NULL */
+  void* draw_cmds;          /* the MERGED global list; room for world x chunk_capacity commands */
+  uint32_t* draw_count;     /* [0] merged command count, [1] merged index total */
+  uint32_t chunk_capacity;  /* commands each rank contributes at most; 0 = the context's max_instances.
+                               A rank that emits more raises MIP_ERR_CAPACITY (never cut silently) */
+  uint32_t flags;           /* MIP_OUT_DEVICE, optionally | MIP_OUT_ASYNC */
+} MipShardedOutputs;
+
+/* One frame of a sharded scene on this rank (collective: every rank calls it with the same
+ * chunk_capacity). frame->first_instance_base must be the shard's first draw_index. */
+int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipShardedOutputs* out);
+
 const char* mip_last_error(const MipContext* ctx);
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out);
 int32_t mip_reset_timings(MipContext* ctx);

@@ -76,6 +76,17 @@ pub struct MipOutputs {
     pub tlas_instances: *mut c_void,
 }
 
+#[repr(C)]
+pub struct MipShardedOutputs {
+    pub model: *mut c_void,
+    pub visible_bitmap: *mut u32,
+    pub world_aabb: *mut c_void,
+    pub draw_cmds: *mut c_void,
+    pub draw_count: *mut u32,
+    pub chunk_capacity: u32,
+    pub flags: u32,
+}
+
 extern "C" {
     pub fn mip_abi_version() -> u32;
     pub fn mip_create(cfg: *const MipConfig, out: *mut *mut MipContext) -> i32;
@@ -94,6 +105,10 @@ extern "C" {
     pub fn mip_wait(ctx: *mut MipContext) -> i32;
     pub fn mip_merge_draw_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
                                 out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+    pub fn mip_comm_unique_id(out_id: *mut u8) -> i32;
+    pub fn mip_comm_init(ctx: *mut MipContext, id: *const u8, rank: u32, world: u32) -> i32;
+    pub fn mip_comm_destroy(ctx: *mut MipContext) -> i32;
+    pub fn mip_run_sharded(ctx: *mut MipContext, frame: *const MipFrame, out: *const MipShardedOutputs) -> i32;
     pub fn mip_last_error(ctx: *const MipContext) -> *const c_char;
     pub fn mip_instance_count(ctx: *const MipContext) -> u32;
 }

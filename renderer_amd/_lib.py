@@ -26,7 +26,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -72,6 +72,18 @@ class MipOutputs(C.Structure):
         ("culled_index_buffer", C.c_void_p),
         ("culled_index_capacity", C.c_uint64),
         ("tlas_instances", C.c_void_p),
+    ]
+
+
+class MipShardedOutputs(C.Structure):
+    _fields_ = [
+        ("model", C.c_void_p),
+        ("visible_bitmap", C.c_void_p),
+        ("world_aabb", C.c_void_p),
+        ("draw_cmds", C.c_void_p),
+        ("draw_count", C.c_void_p),
+        ("chunk_capacity", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
 
 
@@ -138,6 +150,14 @@ def load_library():
     lib.mip_wait.restype = C.c_int32
     lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp, vp, C.c_int32]
     lib.mip_merge_draw_lists.restype = C.c_int32
+    lib.mip_comm_unique_id.argtypes = [vp]
+    lib.mip_comm_unique_id.restype = C.c_int32
+    lib.mip_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    lib.mip_comm_init.restype = C.c_int32
+    lib.mip_comm_destroy.argtypes = [vp]
+    lib.mip_comm_destroy.restype = C.c_int32
+    lib.mip_run_sharded.argtypes = [vp, vp, vp]
+    lib.mip_run_sharded.restype = C.c_int32
     lib.mip_last_error.argtypes = [vp]
     lib.mip_last_error.restype = C.c_char_p
     lib.mip_get_timings.argtypes = [vp, C.POINTER(MipTimings)]

@@ -6,6 +6,9 @@
 #include "instance_pipeline_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is opened with dlopen, never linked
+
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -71,6 +74,11 @@ struct MipContext {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   MipTimings timings{};
   bool pending_async = false;
+  // native sharded exchange (mip_comm_*, mip_run_sharded)
+  ncclComm_t comm = nullptr;
+  uint32_t comm_rank = 0, comm_world = 0;
+  uint32_t* d_send = nullptr;  // this rank's chunk, sized for max_instances commands
+  uint32_t* d_recv = nullptr;  // world chunks
   char err[512] = {0};
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* d_stamps = nullptr;
@@ -134,6 +142,36 @@ int32_t check_device_error(MipContext* ctx) {
   return MIP_OK;
 }
 
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*get_error_string)(ncclResult_t) = nullptr;
+};
+
+// RCCL is an optional dependency: resolved on first use. In a process that already has a
+// librccl.so.1 (torch ships one) dlopen returns that copy.
+const RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      api.get_unique_id = (decltype(api.get_unique_id))dlsym(h, "ncclGetUniqueId");
+      api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(h, "ncclCommInitRank");
+      api.comm_destroy = (decltype(api.comm_destroy))dlsym(h, "ncclCommDestroy");
+      api.all_gather = (decltype(api.all_gather))dlsym(h, "ncclAllGather");
+      api.get_error_string = (decltype(api.get_error_string))dlsym(h, "ncclGetErrorString");
+      if (api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather) api.handle = h;
+    }
+  }
+  return api.handle ? &api : nullptr;
+}
+
 void free_all(MipContext* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
@@ -144,6 +182,9 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_scale);
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
+  if (ctx->comm && rccl()) (void)rccl()->comm_destroy(ctx->comm);
+  (void)hipFree(ctx->d_send);
+  (void)hipFree(ctx->d_recv);
   (void)hipFree(ctx->d_mesh_draw);
   (void)hipFree(ctx->d_blas);
   (void)hipFree(ctx->d_vertices);
@@ -601,6 +642,82 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
     ctx->timings.total_merge_ms += ms;
   }
   return check_device_error(ctx);
+}
+
+int32_t mip_comm_unique_id(uint8_t out_id[MIP_COMM_ID_BYTES]) {
+  if (!out_id) return MIP_ERR_INVALID_ARGUMENT;
+  const RcclApi* r = rccl();
+  if (!r) return MIP_ERR_DEVICE;
+  static_assert(sizeof(ncclUniqueId) == MIP_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (r->get_unique_id(&id) != ncclSuccess) return MIP_ERR_DEVICE;
+  std::memcpy(out_id, &id, sizeof id);
+  return MIP_OK;
+}
+
+int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint32_t rank, uint32_t world) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!id || world == 0 || rank >= world || world > mip::kMaxMergeChunks)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad communicator arguments (rank %u of %u)", rank, world);
+  if (ctx->slots.size() != 1) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "the sharded exchange needs frames_in_flight = 1");
+  if (ctx->comm) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "communicator already initialised");
+  const RcclApi* r = rccl();
+  if (!r) return fail(ctx, MIP_ERR_DEVICE, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  ncclUniqueId nid;
+  std::memcpy(&nid, id, sizeof nid);
+  const ncclResult_t res = r->comm_init_rank(&ctx->comm, (int)world, nid, (int)rank);
+  if (res != ncclSuccess) {
+    ctx->comm = nullptr;
+    return fail(ctx, MIP_ERR_DEVICE, "ncclCommInitRank failed: %s", r->get_error_string ? r->get_error_string(res) : "?");
+  }
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
+  const size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;
+  MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
+  MIP_HIP(ctx, hipMemset(ctx->d_send, 0, stride));
+  MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
+  return MIP_OK;
+}
+
+int32_t mip_comm_destroy(MipContext* ctx) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (ctx->comm && rccl()) {
+    if (int32_t rc = bind_device(ctx)) return rc;
+    if (int32_t rc = sync_all(ctx)) return rc;
+    (void)rccl()->comm_destroy(ctx->comm);
+  }
+  ctx->comm = nullptr;
+  (void)hipFree(ctx->d_send);
+  (void)hipFree(ctx->d_recv);
+  ctx->d_send = ctx->d_recv = nullptr;
+  return MIP_OK;
+}
+
+int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipShardedOutputs* out) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!frame || !out || !out->draw_cmds || !out->draw_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out/draw_cmds/draw_count is NULL");
+  if (!ctx->comm) return fail(ctx, MIP_ERR_NOT_READY, "mip_comm_init has not been called");
+  if (!(out->flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_sharded needs MIP_OUT_DEVICE");
+  const uint32_t cap_max = ctx->max_instances ? ctx->max_instances : 1;
+  const uint32_t cap = (out->chunk_capacity && out->chunk_capacity < cap_max) ? out->chunk_capacity : cap_max;
+  const uint64_t stride = (sizeof(MipShardHeader) + (uint64_t)cap * 20 + 255) / 256 * 256;
+  // 1. this rank's shard, written straight into its chunk (the send buffer always holds max_instances commands)
+  MipOutputs local{};
+  local.model = out->model;
+  local.visible_bitmap = out->visible_bitmap;
+  local.world_aabb = out->world_aabb;
+  local.draw_count = ctx->d_send;
+  local.draw_index_total = ctx->d_send + 1;
+  local.draw_cmds = ctx->d_send + sizeof(MipShardHeader) / 4;
+  local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC;
+  if (int32_t rc = mip_run(ctx, frame, &local)) return rc;
+  // 2. ONE all-gather of the fixed-size chunks, 3. merge — same stream, no host round trip
+  const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
+  if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
+  const bool async = (out->flags & MIP_OUT_ASYNC) != 0;
+  return mip_merge_draw_lists(ctx, ctx->d_recv, ctx->comm_world, stride, out->draw_cmds, out->draw_count, async ? 1 : 0);
 }
 
 const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "null context"; }

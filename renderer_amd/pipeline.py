@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MipConfig, MipError, MipFrame, MipOutputs, MipTimings
+from ._lib import MipConfig, MipError, MipFrame, MipOutputs, MipShardedOutputs, MipTimings
 
 MESH_DTYPE = np.dtype(
     [
@@ -220,6 +220,36 @@ class InstancePipeline:
         rc = self._lib.mip_run_many(self._ctx, C.addressof(frame), C.addressof(arr), len(prepared_outputs), int(steps))
         if rc != 0:
             self._check(rc)
+
+    # -- native sharded exchange (RCCL opened by the library itself) --
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId; create on one rank, share with the others."""
+        buf = (C.c_uint8 * 128)()
+        rc = _lib.load_library().mip_comm_unique_id(buf)
+        if rc != 0:
+            raise MipError(rc, "mip_comm_unique_id failed (is librccl.so.1 loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.mip_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.mip_comm_destroy(self._ctx))
+
+    def run_sharded(self, frame, draw_cmds, draw_count, model=0, visible_bitmap=0, world_aabb=0, chunk_capacity=0,
+                    async_=False):
+        """Shard kernel -> one ncclAllGather -> merge, all inside the library."""
+        out = MipShardedOutputs()
+        out.model = model or None
+        out.visible_bitmap = visible_bitmap or None
+        out.world_aabb = world_aabb or None
+        out.draw_cmds = draw_cmds
+        out.draw_count = draw_count
+        out.chunk_capacity = int(chunk_capacity)
+        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
+        self._check(self._lib.mip_run_sharded(self._ctx, C.addressof(frame), C.addressof(out)))
 
     def wait(self):
         self._check(self._lib.mip_wait(self._ctx))

@@ -570,3 +570,41 @@ def test_partial_instance_updates(ra, oracle_mod):
             p.update_instances(9_990, pos_xyz=np.zeros((20, 3), np.float32))
         with pytest.raises(ra.MipError):
             p.update_instances(0, mesh_id=np.array([64], np.uint32))
+
+
+def test_native_rccl_exchange_world_size_one(ra, oracle_mod):
+    """mip_comm_* / mip_run_sharded: the library opens RCCL itself; one rank gathers with itself."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=150_000)
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds", "visible_bitmap"))
+    dev = torch.device("cuda", 0)
+    uid = ra.InstancePipeline.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        frame = make_frame(s["planes"], s["cam_pos"])
+        merged = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+        count = torch.zeros(2, dtype=torch.int32, device=dev)
+        bitmap = torch.zeros((s["n"] + 31) // 32, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        with pytest.raises(ra.MipError):  # not initialised yet
+            p.run_sharded(frame, merged.data_ptr(), count.data_ptr())
+        p.comm_init(uid, 0, 1)
+        for cap in (0, 60_000):   # full capacity, then a tightened chunk
+            p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), visible_bitmap=bitmap.data_ptr(), chunk_capacity=cap)
+            total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
+            assert total == want["draw_count"] and index_total == want["draw_index_total"]
+            got = merged[:total].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+            assert got.tobytes() == want["draw_cmds"].tobytes()
+            assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
+        with pytest.raises(ra.MipError) as e:   # a chunk smaller than the rank's list is reported
+            p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), chunk_capacity=1000)
+        assert e.value.code == -4
+        p.comm_destroy()
+    with ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=2) as p2:
+        with pytest.raises(ra.MipError):
+            p2.comm_init(uid, 0, 1)
