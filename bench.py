@@ -231,6 +231,8 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
 
 def main():
     args = parse_args()
+    args.steps = max(1, args.steps)
+    args.warmup = max(0, args.warmup)
     # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
     # JSON line on stdout. Everything else this process (and the libraries it loads) prints goes
     # to stderr; the JSON line is written to the saved stdout at the end.
