@@ -31,8 +31,8 @@ def algorithmic_bytes_per_instance(v):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", type=int, default=2, help="1 Box 1k | 2 DamagedHelmet 100k | 3 mixed 1M | 4 mixed 10M")
     ap.add_argument("--instances", type=int, default=None, help="override the per-GPU instance count")
     ap.add_argument("--all-visible", action="store_true", help="every instance inside the frustum (worst-case writes)")
