@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configs reported under 'extra'")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--native-rccl-leg", action="store_true",
+                    help="N>1 only: also time mip_run_sharded (RCCL opened by the library itself). Off by default: it "
+                         "creates a second communicator beside torch's and has only been rehearsed with one rank")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="frames the host keeps in flight (own output buffers each), as the reference's "
                          "per-swapchain-image buffers allow; 1 = strictly serialized steps")
@@ -500,28 +503,29 @@ def main():
             px.wait()
             px.close()
             row["frames_in_flight_2"] = {"instances_per_s": n4 * world * 50 / dt_pipe, "ms_per_step": dt_pipe / 50 * 1e3}
-            # the same exchange without torch on the data path: the library opens RCCL itself
-            # (mip_comm_init / mip_run_sharded), as a native host would drive it
-            ids = [renderer_amd.InstancePipeline.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            pn = renderer_amd.InstancePipeline(max_instances=n4, max_meshes=len(s4["meshes"]), device=local_rank)
-            pn.set_mesh_table(s4["meshes"])
-            pn.set_instances(s4["pos"], s4["rot"], s4["scale"], s4["mesh_id"])
-            pn.comm_init(ids[0], rank, world)
-            merged = torch.empty((world * ex.capacity, 5), dtype=torch.int32, device=device)
-            mcount = torch.zeros(2, dtype=torch.int32, device=device)
-            torch.cuda.synchronize()
+            if args.native_rccl_leg:
+                # the same exchange without torch on the data path: the library opens RCCL itself
+                # (mip_comm_init / mip_run_sharded), as a native host would drive it
+                ids = [renderer_amd.InstancePipeline.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                pn = renderer_amd.InstancePipeline(max_instances=n4, max_meshes=len(s4["meshes"]), device=local_rank)
+                pn.set_mesh_table(s4["meshes"])
+                pn.set_instances(s4["pos"], s4["rot"], s4["scale"], s4["mesh_id"])
+                pn.comm_init(ids[0], rank, world)
+                merged = torch.empty((world * ex.capacity, 5), dtype=torch.int32, device=device)
+                mcount = torch.zeros(2, dtype=torch.int32, device=device)
+                torch.cuda.synchronize()
 
-            def native_step():
-                pn.run_sharded(f4, merged.data_ptr(), mcount.data_ptr(), model=o4.model.data_ptr(),
-                               visible_bitmap=o4.bitmap.data_ptr(), chunk_capacity=ex.capacity, async_=True)
+                def native_step():
+                    pn.run_sharded(f4, merged.data_ptr(), mcount.data_ptr(), model=o4.model.data_ptr(),
+                                   visible_bitmap=o4.bitmap.data_ptr(), chunk_capacity=ex.capacity, async_=True)
 
-            dt_native = time_steps(torch, dist, native_step, 50, 5, True)
-            pn.wait()
-            row["native_rccl"] = {"instances_per_s": n4 * world * 50 / dt_native, "ms_per_step": dt_native / 50 * 1e3,
-                                  "commands_total": int(mcount[0].item())}
-            pn.comm_destroy()
-            pn.close()
+                dt_native = time_steps(torch, dist, native_step, 50, 5, True)
+                pn.wait()
+                row["native_rccl"] = {"instances_per_s": n4 * world * 50 / dt_native, "ms_per_step": dt_native / 50 * 1e3,
+                                      "commands_total": int(mcount[0].item())}
+                pn.comm_destroy()
+                pn.close()
             if rank == 0:
                 result.setdefault("extra", {})["sharded_exchange"] = row
             p4.close()
