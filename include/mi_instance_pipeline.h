@@ -158,6 +158,8 @@ typedef struct MipTimings {
   double last_merge_ms;       /* same for mip_merge_draw_lists */
   double total_merge_ms;
   uint64_t merges;
+  uint64_t graph_frames;      /* frames mip_run_many replayed from recorded launch graphs (counted even without MIP_CFG_TIMING) */
+  uint64_t graph_records;     /* times it had to record a new set of graphs */
 } MipTimings;
 
 /* Chunk header used by mip_merge_draw_lists: what each rank contributes to the
@@ -224,7 +226,11 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out);
 /* Enqueue `steps` frames back to back from compiled code: frame k uses outputs[k % n_outputs]
  * (give at least frames_in_flight output sets). Every output set must carry
  * MIP_OUT_DEVICE | MIP_OUT_ASYNC. Equivalent to calling mip_run `steps` times; exists so that a
- * host in a scripting language does not pay its per-call overhead per frame. */
+ * host in a scripting language does not pay its per-call overhead per frame, and so that the
+ * launches can be recorded once and replayed: when every output set asks for draw commands
+ * and none for the per-triangle stage, whole rounds of ~64 frames go out as one hipGraph
+ * per frame slot (recorded on first use, cached by frame/outputs; MipTimings.graph_frames
+ * counts them); the remainder and every other case are plain mip_run calls. */
 int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
                      uint32_t steps);
 

@@ -95,6 +95,8 @@ class MipTimings(C.Structure):
         ("last_merge_ms", C.c_double),
         ("total_merge_ms", C.c_double),
         ("merges", C.c_uint64),
+        ("graph_frames", C.c_uint64),
+        ("graph_records", C.c_uint64),
     ]
 
 

@@ -38,9 +38,28 @@ struct MipContext {
     uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
-    uint32_t epoch = 0;
+    uint32_t epoch = 0;         // highest tag handed out on this state
+    uint32_t last_tag = 0;      // tag of the last launch (what the level-0 words hold now)
+    uint32_t zero_buf = 2;      // which accumulator buffer is all-zero now: 0, 1, or 2 = both
     bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
   };
+  // mip_run_many replays: per slot one linear hipGraph of `frames` launches with baked tags
+  // base_epoch+1 .. base_epoch+frames (see run_many_graphed).
+  struct FrameGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint32_t base_epoch = 0;
+  };
+  struct GraphSet {
+    MipFrame frame{};
+    std::vector<MipOutputs> outs;
+    uint32_t first_slot = 0, frames_per_slot = 0;
+    uint64_t generation = 0;
+    std::vector<FrameGraph> per_slot;
+  };
+  std::vector<GraphSet> graph_sets;   // small LRU, newest last
+  uint64_t graph_generation = 1;      // bumped whenever something a graph bakes in changes
+  uint32_t graph_round = 64;          // frames per replay round over all slots (MIP_TUNE_GRAPH_ROUND, 0 = off)
   std::vector<FrameSlot> slots;
   uint32_t next_slot = 0;
   hipStream_t stream = nullptr;  // = slots[0].stream: uploads, merges, timing
@@ -172,11 +191,86 @@ const RcclApi* rccl() {
   return api.handle ? &api : nullptr;
 }
 
+// Everything of a launch except the tag: resident inputs, output pointers, prefix state, frame.
+void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame* frame, const MipOutputs* out,
+                      bool device_out, mip::KernelArgs& a) {
+  const uint32_t n = ctx->n;
+  a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
+  a.meshes = ctx->d_meshes; a.mesh_draw = ctx->d_mesh_draw;
+  a.model = out->model ? (device_out ? (float4*)out->model : ctx->s_model) : nullptr;
+  a.bitmap = out->visible_bitmap ? (device_out ? out->visible_bitmap : ctx->s_bitmap) : nullptr;
+  a.cmds = out->draw_cmds ? (device_out ? (uint32_t*)out->draw_cmds : ctx->s_cmds) : nullptr;
+  a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : sl.d_scalars + 0) : nullptr;
+  a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : sl.d_scalars + 1) : nullptr;
+  a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
+  if (out->tlas_instances && device_out) {
+    a.tlas_instances = (uint4*)out->tlas_instances;
+    a.blas_address = ctx->d_blas;
+  }
+  a.status0 = sl.d_status;
+  a.acc1 = sl.d_status + ctx->acc1_offset_words;
+  a.start1 = sl.d_status + ctx->start1_offset_words;
+  a.groups_cap = ctx->groups_cap;
+  a.error_flag = ctx->d_error;
+  a.n = n;
+  a.bitmap_words = (n + 31u) / 32u;
+  a.first_instance_base = frame->first_instance_base;
+  a.first_index_base = frame->first_index_base;
+  std::memcpy(a.planes, frame->planes, sizeof a.planes);
+  std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
+  a.n_tiles = tiles_for(n);
+  a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
+#ifdef MIP_DEBUG_STAMPS
+  a.stamps = ctx->d_stamps;
+  if (const char* env = std::getenv("MIP_DEBUG_SKIP_PUBLISH_TILE")) a.debug_skip_publish_tile = (uint32_t)std::atoi(env) + 1u;
+#endif
+}
+
+// Clears a slot's prefix state when the instance count changed or fewer than `need` tags are left.
+int32_t reset_prefix_state_if_needed(MipContext* ctx, MipContext::FrameSlot& sl, uint32_t need) {
+  if (sl.status_dirty || sl.epoch + need > mip::kMaxEpoch) {
+    MIP_HIP(ctx, hipMemsetAsync(sl.d_status, 0, ctx->status_bytes, sl.stream));
+    sl.status_dirty = false;
+    sl.epoch = sl.last_tag = 0;
+    sl.zero_buf = 2;
+    ctx->graph_generation++;  // recorded tags are meaningless on a cleared state
+  }
+  return MIP_OK;
+}
+
+int32_t validate_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
+  if (!frame || !out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out is NULL");
+  if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
+  if ((out->draw_cmds == nullptr) != (out->draw_count == nullptr))
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_cmds and draw_count go together");
+  if (out->draw_index_total && !out->draw_cmds)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_index_total needs draw_cmds");
+  const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
+  if ((out->flags & MIP_OUT_ASYNC) && !device_out)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
+  if (out->culled_index_buffer) {
+    if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
+    if (!ctx->have_geometry) return fail(ctx, MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
+    if (!out->model || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs model and draw_cmds");
+  }
+  return MIP_OK;
+}
+
+void drop_graphs(MipContext* ctx) {
+  for (auto& gs : ctx->graph_sets)
+    for (auto& fg : gs.per_slot) {
+      if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
+      if (fg.graph) (void)hipGraphDestroy(fg.graph);
+    }
+  ctx->graph_sets.clear();
+}
+
 void free_all(MipContext* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   for (auto& sl : ctx->slots)
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+  drop_graphs(ctx);
   (void)hipFree(ctx->d_pos);
   (void)hipFree(ctx->d_rot);
   (void)hipFree(ctx->d_scale);
@@ -277,6 +371,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_GRAPH_ROUND")) ctx->graph_round = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
       for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
@@ -372,8 +467,10 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
     MIP_HIP(ctx, hipMemcpy(ctx->d_scale, scale, (size_t)n * 4, kind));
     MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind));
   }
-  if (n != ctx->n)
+  if (n != ctx->n) {
     for (auto& sl : ctx->slots) sl.status_dirty = true;  // tile/group geometry changes with n
+    ctx->graph_generation++;                             // and so does every recorded launch
+  }
   ctx->n = n;
   ctx->have_instances = true;
   return MIP_OK;
@@ -419,22 +516,10 @@ int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const voi
 
 int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
-  if (!frame || !out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out is NULL");
-  if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
-  if ((out->draw_cmds == nullptr) != (out->draw_count == nullptr))
-    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_cmds and draw_count go together");
-  if (out->draw_index_total && !out->draw_cmds)
-    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "draw_index_total needs draw_cmds");
+  if (int32_t rc = validate_run(ctx, frame, out)) return rc;
   const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
   const bool async = device_out && (out->flags & MIP_OUT_ASYNC) != 0;
-  if ((out->flags & MIP_OUT_ASYNC) && !device_out)
-    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
   const bool triangles = out->culled_index_buffer != nullptr;
-  if (triangles) {
-    if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
-    if (!ctx->have_geometry) return fail(ctx, MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
-    if (!out->model || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs model and draw_cmds");
-  }
   if (int32_t rc = bind_device(ctx)) return rc;
 
   // Frames rotate over the slots; a slot's stream orders a frame after the frame that last
@@ -449,19 +534,8 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     if (int32_t rc = ensure_staging(ctx, out)) return rc;
 
   mip::KernelArgs a{};
-  a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
-  a.meshes = ctx->d_meshes; a.mesh_draw = ctx->d_mesh_draw;
-  a.model = out->model ? (device_out ? (float4*)out->model : ctx->s_model) : nullptr;
-  a.bitmap = out->visible_bitmap ? (device_out ? out->visible_bitmap : ctx->s_bitmap) : nullptr;
-  a.cmds = out->draw_cmds ? (device_out ? (uint32_t*)out->draw_cmds : ctx->s_cmds) : nullptr;
-  a.draw_count = out->draw_cmds ? (device_out ? out->draw_count : sl.d_scalars + 0) : nullptr;
-  a.index_total = out->draw_cmds ? ((device_out && out->draw_index_total) ? out->draw_index_total : sl.d_scalars + 1) : nullptr;
-  a.world_aabb = out->world_aabb ? (device_out ? (float*)out->world_aabb : ctx->s_aabb) : nullptr;
-  if (out->tlas_instances) {
-    if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "tlas_instances needs MIP_OUT_DEVICE");
-    a.tlas_instances = (uint4*)out->tlas_instances;
-    a.blas_address = ctx->d_blas;
-  }
+  fill_kernel_args(ctx, sl, frame, out, device_out, a);
+  if (out->tlas_instances && !device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "tlas_instances needs MIP_OUT_DEVICE");
   if (triangles) {
     // the instance kernel emits into the slot's scratch list; the triangle stage rewrites
     // indexCount there and the final compaction lands in the caller's buffers
@@ -472,34 +546,15 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     a.draw_count = sl.d_scalars + 2;
     a.src_index_offset = sl.d_tmp_src;
   }
-  a.status0 = sl.d_status;
-  a.acc1 = sl.d_status + ctx->acc1_offset_words;
-  a.start1 = sl.d_status + ctx->start1_offset_words;
-  a.groups_cap = ctx->groups_cap;
-  a.error_flag = ctx->d_error;
-  a.n = n;
-  a.bitmap_words = words;
-  a.first_instance_base = frame->first_instance_base;
-  a.first_index_base = frame->first_index_base;
-  std::memcpy(a.planes, frame->planes, sizeof a.planes);
-  std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
-#ifdef MIP_DEBUG_STAMPS
-  a.stamps = ctx->d_stamps;
-  if (const char* env = std::getenv("MIP_DEBUG_SKIP_PUBLISH_TILE")) a.debug_skip_publish_tile = (uint32_t)std::atoi(env) + 1u;
-#endif
-
-  // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh epoch per launch
-  // tags the level-0 words; the level-1 accumulators alternate between two buffers, the
-  // kernel zeroing the other one. Launches without draw commands do not touch the state.
-  a.n_tiles = tiles_for(n);
-  a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
+  // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh tag per launch marks
+  // the level-0 words; the level-1 accumulators alternate between two buffers by tag parity,
+  // the kernel zeroing the other one. Launches without draw commands do not touch the state.
   if (a.cmds && n) {
-    if (sl.status_dirty || sl.epoch >= mip::kMaxEpoch) {
-      MIP_HIP(ctx, hipMemsetAsync(sl.d_status, 0, ctx->status_bytes, stream));
-      sl.status_dirty = false;
-      sl.epoch = 0;
-    }
-    a.epoch = ++sl.epoch;
+    if (int32_t rc = reset_prefix_state_if_needed(ctx, sl, 2)) return rc;
+    uint32_t e = sl.epoch + 1;
+    if (sl.zero_buf != 2 && (e & 1u) != sl.zero_buf) ++e;  // must accumulate in the zeroed buffer
+    a.epoch = sl.epoch = sl.last_tag = e;
+    sl.zero_buf = (e & 1u) ^ 1u;
   }
 
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0;
@@ -584,13 +639,135 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   return check_device_error(ctx);
 }
 
+// mip_run_many with the launches recorded once and replayed: per slot a linear hipGraph of
+// G launches of the instance kernel. A launch's only per-frame state is its prefix tag; a chain
+// bakes the tags base+1 .. base+G. Replaying the same tags is sound because every launch rewrites
+// every level-0 word and group start it later reads, so the only stale tag a word can hold is
+// the previous launch's — base+G before the chain's first launch (G >= 2) — and because G is
+// even, so the accumulator buffer the first launch adds into is the one the last launch zeroed.
+static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
+                                uint32_t rounds, uint32_t frames_per_slot) {
+  const uint32_t F = (uint32_t)ctx->slots.size();
+  const uint32_t G = frames_per_slot;
+  for (auto& sl : ctx->slots)
+    if (int32_t rc = reset_prefix_state_if_needed(ctx, sl, G + 2)) return rc;
+
+  MipContext::GraphSet* set = nullptr;
+  for (size_t i = 0; i < ctx->graph_sets.size();) {
+    auto& gs = ctx->graph_sets[i];
+    if (gs.generation != ctx->graph_generation) {  // recorded against another instance count or a cleared state
+      for (auto& fg : gs.per_slot) {
+        if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
+        if (fg.graph) (void)hipGraphDestroy(fg.graph);
+      }
+      ctx->graph_sets.erase(ctx->graph_sets.begin() + (long)i);
+      continue;
+    }
+    if (gs.first_slot == ctx->next_slot && gs.frames_per_slot == G && gs.outs.size() == n_outputs &&
+        std::memcmp(&gs.frame, frame, sizeof(MipFrame)) == 0 &&
+        std::memcmp(gs.outs.data(), outputs, sizeof(MipOutputs) * n_outputs) == 0)
+      set = &gs;
+    ++i;
+  }
+  if (set)
+    for (uint32_t i = 0; i < F; ++i)
+      if (ctx->slots[(set->first_slot + i) % F].last_tag == set->per_slot[i].base_epoch + 1) set = nullptr;  // cannot happen; re-record if it does
+  if (!set) {
+    if (ctx->graph_sets.size() >= 4) {
+      for (auto& fg : ctx->graph_sets.front().per_slot) {
+        if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
+        if (fg.graph) (void)hipGraphDestroy(fg.graph);
+      }
+      ctx->graph_sets.erase(ctx->graph_sets.begin());
+    }
+    ctx->graph_sets.emplace_back();
+    MipContext::GraphSet& gs = ctx->graph_sets.back();
+    gs.frame = *frame;
+    gs.outs.assign(outputs, outputs + n_outputs);
+    gs.first_slot = ctx->next_slot;
+    gs.frames_per_slot = G;
+    gs.generation = ctx->graph_generation;
+    gs.per_slot.resize(F);
+    for (uint32_t i = 0; i < F; ++i) {
+      MipContext::FrameSlot& sl = ctx->slots[(gs.first_slot + i) % F];
+      MipContext::FrameGraph& fg = gs.per_slot[i];
+      uint32_t base = sl.epoch > sl.last_tag ? sl.epoch : sl.last_tag;
+      if (sl.zero_buf != 2 && ((base + 1) & 1u) != sl.zero_buf) ++base;
+      fg.base_epoch = base;
+      MIP_HIP(ctx, hipGraphCreate(&fg.graph, 0));
+      hipGraphNode_t prev = nullptr;
+      for (uint32_t j = 0; j < G; ++j) {
+        const MipOutputs* out = &outputs[(i + j * F) % n_outputs];
+        mip::KernelArgs a{};
+        fill_kernel_args(ctx, sl, frame, out, true, a);
+        a.epoch = base + 1 + j;
+        void* params[1] = {&a};
+        hipKernelNodeParams kp{};
+        kp.func = (void*)mip::mip_instance_pipeline_kernel;
+        kp.gridDim = dim3(a.n_tiles);
+        kp.blockDim = dim3(mip::kTile);
+        kp.sharedMemBytes = ctx->lds_pad;
+        kp.kernelParams = params;
+        kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        MIP_HIP(ctx, hipGraphAddKernelNode(&node, fg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
+      }
+      MIP_HIP(ctx, hipGraphInstantiate(&fg.exec, fg.graph, nullptr, nullptr, 0));
+    }
+    ctx->timings.graph_records += 1;
+    set = &gs;
+  }
+
+  for (uint32_t r = 0; r < rounds; ++r)
+    for (uint32_t i = 0; i < F; ++i) {
+      MipContext::FrameSlot& sl = ctx->slots[(set->first_slot + i) % F];
+      const MipContext::FrameGraph& fg = set->per_slot[i];
+      const uint32_t first_buf = (fg.base_epoch + 1) & 1u;
+      if (sl.zero_buf != 2 && sl.zero_buf != first_buf)  // other launches ran in between: zero the buffer the chain starts in
+        MIP_HIP(ctx, hipMemsetAsync(sl.d_status + ctx->acc1_offset_words + (size_t)first_buf * ctx->groups_cap * mip::kAccStrideWords, 0,
+                                    (size_t)ctx->groups_cap * mip::kAccStrideWords * 8, sl.stream));
+      MIP_HIP(ctx, hipGraphLaunch(fg.exec, sl.stream));
+      sl.last_tag = fg.base_epoch + G;
+      if (sl.epoch < sl.last_tag) sl.epoch = sl.last_tag;
+      sl.zero_buf = first_buf;  // G is even: the last launch zeroed the buffer the first one uses
+      ctx->timings.graph_frames += G;
+    }
+  ctx->pending_async = true;
+  return MIP_OK;
+}
+
 int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs, uint32_t steps) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!frame || !outputs || n_outputs == 0) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/outputs is NULL or empty");
-  for (uint32_t k = 0; k < n_outputs; ++k)
+  bool plain = true;  // only launches of the instance kernel alone are recorded
+  for (uint32_t k = 0; k < n_outputs; ++k) {
     if ((outputs[k].flags & (MIP_OUT_DEVICE | MIP_OUT_ASYNC)) != (MIP_OUT_DEVICE | MIP_OUT_ASYNC))
       return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_many needs MIP_OUT_DEVICE | MIP_OUT_ASYNC outputs");
-  for (uint32_t k = 0; k < steps; ++k)
+    if (outputs[k].culled_index_buffer || !outputs[k].draw_cmds) plain = false;
+  }
+  uint32_t done = 0;
+  const uint32_t F = (uint32_t)ctx->slots.size();
+  if (plain && ctx->graph_round && ctx->n && !(ctx->cfg_flags & MIP_CFG_TIMING)) {
+    // a round = the smallest run after which slot and output rotation repeat, with an even
+    // number of frames per slot, scaled up to about graph_round frames
+    uint32_t a = F, b = n_outputs;
+    while (b) { const uint32_t t = a % b; a = b; b = t; }
+    const uint64_t unit = 2ull * F / a * n_outputs;
+    if (unit <= ctx->graph_round && steps >= unit) {
+      const uint32_t round = (uint32_t)(ctx->graph_round / unit * unit);
+      const uint32_t rounds = steps / round;
+      if (rounds) {
+        for (uint32_t k = 0; k < n_outputs; ++k)
+          if (int32_t rc = validate_run(ctx, frame, &outputs[k])) return rc;
+        if (int32_t rc = bind_device(ctx)) return rc;
+        if (int32_t rc = run_many_graphed(ctx, frame, outputs, n_outputs, rounds, round / F)) return rc;
+        done = rounds * round;
+      }
+    }
+  }
+  // the rest (or everything) one launch at a time; round % n_outputs == 0 keeps the rotation
+  for (uint32_t k = done; k < steps; ++k)
     if (int32_t rc = mip_run(ctx, frame, &outputs[k % n_outputs])) return rc;
   return MIP_OK;
 }

@@ -478,6 +478,70 @@ def test_run_many_and_pipelined_exchange(ra, oracle_mod):
         dist.destroy_process_group()
 
 
+def test_run_many_replays_recorded_launch_graphs(ra, oracle_mod):
+    """mip_run_many sends whole rounds as one hipGraph per frame slot. Replays, replays after
+    single launches changed the accumulator parity, other output rotations and a changed
+    instance count all have to give the oracle's list in every output set."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    big = ra.scene.make_scene(3, n=150_000)
+    small = ra.scene.make_scene(3, n=33_000)
+    want = {id(x): run_oracle(oracle_mod, x, threads=8, want=("draw_cmds",)) for x in (big, small)}
+    dev = torch.device("cuda", 0)
+
+    def check(sets, s, what):
+        for k, (cmds, scal, _) in enumerate(sets):
+            w = want[id(s)]
+            count = int(scal[0].item())
+            assert count == w["draw_count"] and int(scal[1].item()) == w["draw_index_total"], (what, k)
+            got = cmds[:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+            assert got.tobytes() == w["draw_cmds"].tobytes(), (what, k)
+            cmds.zero_()
+            scal.zero_()
+        torch.cuda.synchronize()
+
+    for frames, n_sets in ((1, 1), (2, 2), (3, 3), (2, 3)):
+        with ra.InstancePipeline(max_instances=big["n"], max_meshes=64, frames_in_flight=frames) as p:
+            p.set_mesh_table(big["meshes"])
+            p.set_instances(big["pos"], big["rot"], big["scale"], big["mesh_id"])
+            sets = []
+            for _ in range(n_sets):
+                cmds = torch.zeros((big["n"], 5), dtype=torch.int32, device=dev)
+                scal = torch.zeros(8, dtype=torch.int32, device=dev)
+                sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                                                            draw_index_total=scal.data_ptr() + 4)))
+            torch.cuda.synchronize()
+            frame = make_frame(big["planes"], big["cam_pos"])
+            outs = [x[2] for x in sets]
+            tag = (frames, n_sets)
+            p.run_many(frame, outs, 200)  # rounds + a remainder of single launches
+            p.wait()
+            t = p.timings()
+            assert t["graph_records"] == 1 and 128 <= t["graph_frames"] <= 200, t
+            check(sets, big, (tag, "first"))
+            p.run_many(frame, outs, 130)
+            p.wait()
+            check(sets, big, (tag, "again"))
+            # odd numbers of single launches flip the accumulator parity under the recorded chains
+            for k in range(3):
+                p.run_prepared(p.frame_ref(frame), outs[k % n_sets])
+            p.wait()
+            p.run_many(frame, outs, 64 * 3)
+            p.wait()
+            check(sets, big, (tag, "after singles"))
+            p.run_prepared(p.frame_ref(frame), outs[0])
+            p.wait()
+            check(sets[:1], big, (tag, "single after replay"))
+            # a new instance count invalidates everything recorded
+            p.set_instances(small["pos"], small["rot"], small["scale"], small["mesh_id"])
+            p.run_many(make_frame(small["planes"], small["cam_pos"]), outs, 150)
+            p.wait()
+            check(sets, small, (tag, "resized"))
+            assert p.timings()["graph_records"] >= 2
+
+
 def test_epoch_tag_wrap_clears_the_prefix_state(ra, oracle_mod):
     """The 23-bit launch tag wraps after 8 388 606 launches per frame slot; the host then clears the
     prefix state and restarts at 1. Start two launches before the wrap and cross it."""
@@ -500,6 +564,23 @@ for frames in (1, 2):
         for k in range(12):
             got = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))
             assert got["draw_count"] == want["draw_count"] and got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes(), (frames, k)
+# recorded chains need G+2 tags: a context that starts next to the wrap clears its state first
+import torch
+from renderer_amd.pipeline import make_frame
+dev = torch.device("cuda", 0)
+with renderer_amd.InstancePipeline(s["n"], 64, frames_in_flight=2) as p:
+    p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    sets = []
+    for _ in range(2):
+        cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev); scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
+    torch.cuda.synchronize()
+    for rep in range(3):
+        p.run_many(make_frame(s["planes"], s["cam_pos"]), [x[2] for x in sets], 100); p.wait()
+        for cmds, scal, _ in sets:
+            c = int(scal[0].item())
+            assert c == want["draw_count"] and cmds[:c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), rep
+    assert p.timings()["graph_frames"] == 3 * 64
 print("WRAP_OK")
 '''
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
