@@ -234,6 +234,21 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out);
 int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
                      uint32_t steps);
 
+/* Row f-4, second consumer — the shadow pass's per-light draw lists
+ * (src/renderer/systems/shadow_mapping.rs:405-478: for every light, for every mesh entity,
+ * pick_lod(index_buffers, light_position, mesh_position) and cmd_draw_indexed(index_count, 1,
+ * 0, 0, draw_index); nothing is culled). For light l and resident instance i
+ *   out_cmds[l*n + i] = { index_len[lod], 1, index_offset[lod], vertex_offset,
+ *                         first_instance_base + i }
+ * over the consolidated buffers (as cull_pass addresses them, cull_pipeline.rs:540-553), so the
+ * shadow pass becomes one vkCmdDrawIndexedIndirect(buffer, l*n*20, n, 20) per light.
+ * light_pos_xyz: n_lights x 3 host floats, 1 <= n_lights <= MIP_MAX_LIGHTS (the 4x4 shadow atlas,
+ * shadow_mapping.rs:24). out_cmds: DEVICE pointer, n_lights * n * 20 bytes. async != 0: returns
+ * after enqueueing on the context's stream (mip_wait to finish). */
+#define MIP_MAX_LIGHTS 16
+int32_t mip_light_draw_lists(MipContext* ctx, const float* light_pos_xyz, uint32_t n_lights,
+                             uint32_t first_instance_base, void* out_cmds, int32_t async);
+
 /* Block until everything enqueued by this context has finished; reports a
  * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
 int32_t mip_wait(MipContext* ctx);

@@ -105,6 +105,9 @@ extern "C" {
     pub fn mip_wait(ctx: *mut MipContext) -> i32;
     pub fn mip_merge_draw_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
                                 out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+    /// Shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, light-major, into device memory.
+    pub fn mip_light_draw_lists(ctx: *mut MipContext, light_pos_xyz: *const f32, n_lights: u32, first_instance_base: u32,
+                                out_cmds: *mut c_void, async_: i32) -> i32;
     pub fn mip_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn mip_comm_init(ctx: *mut MipContext, id: *const u8, rank: u32, world: u32) -> i32;
     pub fn mip_comm_destroy(ctx: *mut MipContext) -> i32;

@@ -19,4 +19,5 @@ from .oracle import (  # noqa: F401
     camera_pv,
     cull_all_triangles,
     tlas_instances,
+    light_draw_lists,
 )

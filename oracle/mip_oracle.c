@@ -595,3 +595,22 @@ void orc_tlas_instances(uint32_t n, const float* model, const uint32_t* mesh_id,
     memcpy(o + 56, &blas, 8);
   }
 }
+
+/* src/renderer/systems/shadow_mapping.rs:405-478: every light draws every mesh entity with the LOD
+ * picked against the LIGHT's position; firstIndex/vertexOffset address the consolidated buffers
+ * as cull_pass does (cull_pipeline.rs:540-553). */
+void orc_light_draw_lists(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id, const OrcMesh* meshes,
+                          const float* light_pos_xyz, uint32_t n_lights, uint32_t first_instance_base,
+                          OrcDrawCmd* out) {
+  for (uint32_t l = 0; l < n_lights; ++l)
+    for (uint32_t i = 0; i < n; ++i) {
+      const OrcMesh* mesh = &meshes[mesh_id[i]];
+      const uint32_t lod = orc_pick_lod(mesh->n_lods, &light_pos_xyz[(size_t)l * 3], &pos_xyz[(size_t)i * 3]);
+      OrcDrawCmd* c = &out[(size_t)l * n + i];
+      c->indexCount = mesh->index_len[lod];
+      c->instanceCount = 1;
+      c->firstIndex = mesh->index_offset[lod];
+      c->vertexOffset = mesh->vertex_offset;
+      c->firstInstance = first_instance_base + i;
+    }
+}

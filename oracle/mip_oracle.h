@@ -165,6 +165,12 @@ void orc_src_index_offsets(uint32_t n, const float* pos_xyz, const uint32_t* mes
 void orc_tlas_instances(uint32_t n, const float* model, const uint32_t* mesh_id, const uint64_t* blas_address,
                         uint32_t first_instance_base, void* out);
 
+/* ---- row f-4, second consumer: the shadow pass's per-light draw lists
+ * (src/renderer/systems/shadow_mapping.rs:405-478). out: n_lights x n commands, light-major. */
+void orc_light_draw_lists(uint32_t n, const float* pos_xyz, const uint32_t* mesh_id, const OrcMesh* meshes,
+                          const float* light_pos_xyz, uint32_t n_lights, uint32_t first_instance_base,
+                          OrcDrawCmd* out);
+
 /* CameraMatrices.pv = projection * view for orc_project_camera's camera (column-major). */
 void orc_camera_pv(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect, float fovy_degrees,
                    float near_z, float far_z, float pv[16]);

@@ -147,6 +147,19 @@ def tlas_instances(model, mesh_id, blas_address=None, first_instance_base=0):
     return out
 
 
+def light_draw_lists(pos_xyz, mesh_id, meshes, light_pos_xyz, first_instance_base=0):
+    """shadow_mapping.rs:405-478 as indirect lists: (n_lights, n) commands."""
+    pos = _f32(pos_xyz).reshape(-1, 3)
+    n = len(pos)
+    mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32)
+    meshes = np.ascontiguousarray(meshes, dtype=ORC_MESH_DTYPE)
+    lights = _f32(light_pos_xyz).reshape(-1, 3)
+    out = np.zeros((len(lights), n), DRAW_CMD_DTYPE)
+    lib().orc_light_draw_lists(C.c_uint32(n), _p(pos), _p(mesh_id), _p(meshes), _p(lights), C.c_uint32(len(lights)),
+                               C.c_uint32(first_instance_base), _p(out))
+    return out
+
+
 def camera_pv(cam_pos=(0.0, 1.0, 2.0), cam_rot_ijkw=(0.0, 0.0, 0.0, 1.0), aspect=2.0, fovy_degrees=70.0,
               near=0.1, far=100.0):
     pv = np.empty(16, np.float32)

@@ -772,6 +772,41 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
   return MIP_OK;
 }
 
+int32_t mip_light_draw_lists(MipContext* ctx, const float* light_pos_xyz, uint32_t n_lights, uint32_t first_instance_base,
+                             void* out_cmds, int32_t async) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
+  if (!light_pos_xyz || !out_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+  static_assert(MIP_MAX_LIGHTS == mip::kMaxLights, "light limit");
+  if (n_lights == 0 || n_lights > MIP_MAX_LIGHTS)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_lights %u outside 1..%u", n_lights, (unsigned)MIP_MAX_LIGHTS);
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (ctx->n) {
+    mip::LightListArgs a{};
+    a.pos = ctx->d_pos;
+    a.mesh_id = ctx->d_mesh_id;
+    a.meshes = ctx->d_meshes;
+    a.mesh_draw = ctx->d_mesh_draw;
+    a.out = (uint32_t*)out_cmds;
+    a.n = ctx->n;
+    a.n_lights = n_lights;
+    a.first_instance_base = first_instance_base;
+    std::memcpy(a.light, light_pos_xyz, (size_t)n_lights * 12);
+    const bool aligned = (ctx->n % 4u) == 0 && ((uintptr_t)out_cmds % 16u) == 0;
+    if (aligned)
+      hipLaunchKernelGGL(mip::mip_light_draw_lists_kernel<true>, dim3(tiles_for(ctx->n)), dim3(mip::kTile), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(mip::mip_light_draw_lists_kernel<false>, dim3(tiles_for(ctx->n)), dim3(mip::kTile), 0, ctx->stream, a);
+    MIP_HIP(ctx, hipGetLastError());
+  }
+  if (async) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return check_device_error(ctx);
+}
+
 int32_t mip_wait(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;

@@ -260,6 +260,13 @@ class InstancePipeline:
                                                    int(chunk_stride_bytes), out_cmds_ptr,
                                                    out_count_ptr, 1 if async_ else 0))
 
+    def light_draw_lists(self, light_pos_xyz, out_cmds_ptr, first_instance_base=0, async_=False):
+        """Per-light shadow-pass draw lists (shadow_mapping.rs:405-478): n_lights x n commands, light-major,
+        into device memory at out_cmds_ptr."""
+        lights = np.ascontiguousarray(light_pos_xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self._lib.mip_light_draw_lists(self._ctx, lights.ctypes.data, len(lights), int(first_instance_base),
+                                                   out_cmds_ptr, 1 if async_ else 0))
+
     # -- diagnostics --
     def timings(self):
         t = MipTimings()

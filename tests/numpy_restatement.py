@@ -109,6 +109,22 @@ def draw_commands(pos, mesh_id, culled, meshes, cam_pos, first_instance_base=0, 
                 total=int(len_vis.sum()) & 0xFFFFFFFF)
 
 
+def light_draw_lists(pos, mesh_id, meshes, lights, first_instance_base=0):
+    """shadow_mapping.rs:405-478: every light x every instance, LOD picked against the light."""
+    out = []
+    for lp in np.asarray(lights, F).reshape(-1, 3):
+        with np.errstate(all="ignore"):
+            d = lp[None, :] - pos.astype(F)
+            sq = F(0.0) + ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+            far = np.sqrt(sq) > F(10.0)
+        lod = (far & (meshes["n_lods"][mesh_id] > 1)).astype(np.int64)
+        out.append(np.stack([meshes["index_len"][mesh_id, lod].astype(np.uint32), np.ones(len(pos), np.uint32),
+                             meshes["index_offset"][mesh_id, lod].astype(np.uint32),
+                             meshes["vertex_offset"][mesh_id].astype(np.int32).view(np.uint32),
+                             (np.arange(len(pos)) + first_instance_base).astype(np.uint32)], axis=1))
+    return np.stack(out)
+
+
 def run(s, first_instance_base=0, first_index_base=0):
     model = model_matrices(s["pos"], s["rot"], s["scale"])
     mn = s["meshes"]["aabb_min"][s["mesh_id"]]

@@ -478,6 +478,40 @@ def test_run_many_and_pipelined_exchange(ra, oracle_mod):
         dist.destroy_process_group()
 
 
+def test_light_draw_lists(ra, oracle_mod):
+    """Row f-4, shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, bit-exact, for instance
+    counts that do and do not keep the rows 16-byte aligned, partial tiles, 1 and 16 lights."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    for n, n_lights in ((1, 1), (255, 3), (1024, 16), (100_003, 4), (120_000, 5)):
+        s = ra.scene.make_scene(3, n=n)
+        pos = s["pos"].copy()
+        if n > 100:
+            pos[17] = np.nan
+            pos[33] = np.inf
+        lights = rng.uniform(-40, 40, size=(n_lights, 3)).astype(np.float32)
+        lights[0] = pos[0]
+        want = oracle_mod.light_draw_lists(pos, s["mesh_id"], s["meshes"], lights, first_instance_base=3)
+        with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(pos, s["rot"], s["scale"], s["mesh_id"])
+            out = torch.full((n_lights * n + 1, 5), -1, dtype=torch.int32, device=dev)
+            p.light_draw_lists(lights, out.data_ptr(), first_instance_base=3)
+            got = out.cpu().numpy()
+            assert got[:-1].tobytes() == want.tobytes(), (n, n_lights)
+            assert (got[-1] == -1).all()  # nothing past the last list
+            out2 = torch.full((n_lights * n + 2, 5), -1, dtype=torch.int32, device=dev)  # 4-byte-aligned destination only
+            p.light_draw_lists(lights, out2.data_ptr() + 20, first_instance_base=3, async_=True)
+            p.wait()
+            assert out2.cpu().numpy()[1:-1].tobytes() == want.tobytes(), (n, n_lights, "unaligned")
+            with pytest.raises(ra.MipError):
+                p.light_draw_lists(np.zeros((17, 3), np.float32), out.data_ptr())
+            with pytest.raises(ra.MipError):
+                p.light_draw_lists(np.zeros((0, 3), np.float32), out.data_ptr())
+
+
 def test_run_many_replays_recorded_launch_graphs(ra, oracle_mod):
     """mip_run_many sends whole rounds as one hipGraph per frame slot. Replays, replays after
     single launches changed the accumulator parity, other output rotations and a changed

@@ -200,6 +200,25 @@ def test_numpy_restatement_agrees(oracle_mod, special):
     assert a["draw_index_total"] == b["cmds"]["total"]
 
 
+def test_light_draw_lists_against_numpy(oracle_mod):
+    """Row f-4, shadow pass: every light lists every instance; only the LOD depends on the light."""
+    import numpy_restatement as npr
+    from renderer_amd import scene
+
+    s = scene.make_scene(3, n=5000)
+    pos = s["pos"].copy()
+    pos[7] = np.nan  # NaN distance compares false: LOD 0 (helpers.rs:6)
+    lights = np.array([[30, 20, -40.1], [0.1, 17.0, -0.1], [0.0, 0.0, 0.0], pos[11]], np.float32)  # main.rs:368-382 + on top of an instance
+    got = oracle_mod.light_draw_lists(pos, s["mesh_id"], s["meshes"], lights, first_instance_base=9)
+    want = npr.light_draw_lists(pos, s["mesh_id"], s["meshes"], lights, first_instance_base=9)
+    assert got.shape == (4, 5000)
+    assert np.array_equal(got.view(np.uint32).reshape(4, 5000, 5), want)
+    m = s["meshes"][s["mesh_id"][7]]
+    assert all(got[l, 7]["indexCount"] == m["index_len"][0] for l in range(4))
+    assert got[3, 11]["indexCount"] == s["meshes"][s["mesh_id"][11]]["index_len"][0]  # distance 0: LOD 0
+    assert len({int(got[l]["indexCount"].astype(np.uint64).sum()) for l in range(4)}) > 1  # the lights do differ
+
+
 def test_mesh_id_out_of_range_is_rejected(oracle_mod):
     from renderer_amd import scene
 
