@@ -186,6 +186,66 @@ def cpu_baseline(scene_dict, seconds):
     }
 
 
+def light_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
+    """Row f-4 (shadow pass): per-light draw lists for the 4 lights the reference spawns (main.rs:368-382)."""
+    n = s["n"]
+    pl = renderer_amd.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), device=local_rank)
+    pl.set_mesh_table(s["meshes"])
+    pl.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    lights = np.array([[30, 20, -40.1], [0.1, 17, -0.1], [-30, 20, 40.1], [0, 30, 0]], np.float32)
+    lists = torch.empty((len(lights) * n, 5), dtype=torch.int32, device=device)
+    for _ in range(20):
+        pl.light_draw_lists(lights, lists.data_ptr(), async_=True)
+    pl.wait()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        pl.light_draw_lists(lights, lists.data_ptr(), async_=True)
+    pl.wait()
+    dt = (time.perf_counter() - t0) / 200
+    pl.close()
+    return {
+        "instances": n, "lights": len(lights), "ms_per_launch": dt * 1e3,
+        "algorithmic_GBps": n * (16 + 20 * len(lights)) / dt / 1e9,
+        "note": "shadow_mapping.rs:405-478 as indirect lists: 16 B read + 20 B x lights written per instance",
+    }
+
+
+def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_rank):
+    """BASELINE config 5 (extension, no reference semantics): 256 k instances of a 19-joint figure, each
+    with its own pose: palette + skinned bounds kernel, then the instance kernel."""
+    s = scene.make_skinned_scene()
+    n, j = s["n"], len(s["skeleton"]["parent"])
+    p = renderer_amd.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), device=local_rank)
+    p.set_mesh_table(s["meshes"])
+    p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    sk = s["skeleton"]
+    p.set_skeleton(sk["parent"], sk["inverse_bind"], sk["joint_box"])
+    poses = torch.from_numpy(s["poses"]).to(device)
+    torch.cuda.synchronize()
+    p.set_poses_device(poses.data_ptr(), n)
+    o = DeviceOutputs(torch, n, device)
+    palette = torch.empty((n, j, 16), dtype=torch.float32, device=device)
+    frame = make_frame(s["planes"], s["cam_pos"])
+    for _ in range(5):
+        p.run_skinned(frame, palette=palette.data_ptr(), async_=True, **o.kwargs())
+    p.wait()
+    count = int(o.scalars[0].item())
+    steps = 50
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p.run_skinned(frame, palette=palette.data_ptr(), async_=True, **o.kwargs())
+    p.wait()
+    dt = (time.perf_counter() - t0) / steps
+    p.close()
+    nbytes = n * (36 + j * 40 + j * 64 + 1) + n * (36 + 64 + 0.125 + 1) + count * 20
+    return {
+        "instances": n, "joints": j, "ms_per_frame": dt * 1e3, "instances_per_s": n / dt, "emitted_fraction": count / n,
+        "algorithmic_GBps": nbytes / dt / 1e9,
+        "note": "per instance: 19 x (40 B pose read + 64 B palette written) in the skinning kernel, then the instance kernel's "
+                "100 B + 20 B per command; parity is against this repository's oracle only",
+    }
+
+
 def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, with_cpu):
     """generate_work.comp:68-200 for every emitted command of the headline scene (synthetic torus
     geometry with the DamagedHelmet triangle counts): frame = instance kernel + triangle kernel +
@@ -466,29 +526,17 @@ def main():
 
     if not args.no_extra and not distributed and args.config == 2 and args.instances is None and rank == 0:
         # row f-1 (next tier, not the headline): per-triangle cull + index-stream append on the same scene
-        result.setdefault("extra", {})["triangle_cull"] = triangle_leg(torch, renderer_amd, scene, make_frame, s, device,
-                                                                        local_rank, not args.no_cpu_baseline)
+        try:
+            result.setdefault("extra", {})["triangle_cull"] = triangle_leg(torch, renderer_amd, scene, make_frame, s, device,
+                                                                            local_rank, not args.no_cpu_baseline)
+        except Exception as e:  # noqa: BLE001
+            result.setdefault("extra", {})["triangle_cull"] = {"error": f"{type(e).__name__}: {e}"}
 
-        # row f-4 (shadow pass): per-light draw lists for the 4 lights the reference spawns (main.rs:368-382)
-        pl = renderer_amd.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), device=local_rank)
-        pl.set_mesh_table(s["meshes"])
-        pl.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-        lights = np.array([[30, 20, -40.1], [0.1, 17, -0.1], [-30, 20, 40.1], [0, 30, 0]], np.float32)
-        lists = torch.empty((len(lights) * n, 5), dtype=torch.int32, device=device)
-        for _ in range(20):
-            pl.light_draw_lists(lights, lists.data_ptr(), async_=True)
-        pl.wait()
-        t0 = time.perf_counter()
-        for _ in range(200):
-            pl.light_draw_lists(lights, lists.data_ptr(), async_=True)
-        pl.wait()
-        dt_l = (time.perf_counter() - t0) / 200
-        pl.close()
-        result["extra"]["light_draw_lists"] = {
-            "instances": n, "lights": len(lights), "ms_per_launch": dt_l * 1e3,
-            "algorithmic_GBps": n * (16 + 20 * len(lights)) / dt_l / 1e9,
-            "note": "shadow_mapping.rs:405-478 as indirect lists: 16 B read + 20 B x lights written per instance",
-        }
+        for label, leg in (("light_draw_lists", light_leg), ("skinned_256k", skinned_leg)):
+            try:  # an extra leg must never cost the headline line
+                result["extra"][label] = leg(torch, renderer_amd, scene, make_frame, s, device, local_rank)
+            except Exception as e:  # noqa: BLE001
+                result["extra"][label] = {"error": f"{type(e).__name__}: {e}"}
 
     if distributed and not args.no_extra:
         try:

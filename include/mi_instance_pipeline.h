@@ -249,6 +249,36 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
 int32_t mip_light_draw_lists(MipContext* ctx, const float* light_pos_xyz, uint32_t n_lights,
                              uint32_t first_instance_base, void* out_cmds, int32_t async);
 
+/* ---- Extension: skinned instances (BASELINE config 5) ----------------------------------------
+ * NOT a reference behaviour: farnoy/renderer has no skins, joints or animation (SURVEY.md
+ * section 8, top table). Specified from glTF 2.0 section 3.7.3 and checked against this repository's
+ * oracle only. One skeleton per context, shared by every instance:
+ *   parent[k]        index of the parent joint, < k, or -1 (parents precede children)
+ *   inverse_bind     n_joints x 16 floats, column-major mat4 (skin.inverseBindMatrices; rows 0..2 used)
+ *   joint_box        n_joints x 6 floats: min xyz, max xyz of the bind-pose vertices weighted to
+ *                    joint k, in mesh space (min > max: the joint binds no vertex)
+ * 1 <= n_joints <= MIP_MAX_JOINTS. Host pointers; copied. */
+#define MIP_MAX_JOINTS 32
+#define MIP_POSE_FLOATS 10 /* per joint: translation xyz, rotation quaternion ijkw, scale xyz (the LOCAL TRS) */
+int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* inverse_bind,
+                         const float* joint_box, uint32_t n_joints);
+
+/* The animated pose of every instance: n x n_joints x MIP_POSE_FLOATS floats, instance-major.
+ * n must equal the resident instance count. device == 0: host pointer, copied. device != 0: a
+ * DEVICE pointer that is borrowed, not copied — an animation system rewrites it between frames
+ * and keeps it alive while frames that read it are in flight. */
+int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_t device);
+
+/* One frame of skinned instances. Per instance and joint
+ *   L_k = T*R*S of the pose, G_k = G_parent * L_k, J_k = G_k * inverse_bind_k   (affine, fp32)
+ * the palette (n x n_joints mat4, column-major, DEVICE pointer, may be NULL) receives J_k; the
+ * instance's world box becomes the union over joints of (M * J_k) * joint_box_k, M being its
+ * model matrix, and replaces the rigid box in the frustum test; everything else — model[],
+ * bitmap, draw commands, count, TLAS rows — is produced as by mip_run (out->world_aabb receives
+ * the skinned box). out must carry MIP_OUT_DEVICE; culled_index_buffer is not supported (the
+ * per-triangle stage does not skin vertices). */
+int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, void* palette);
+
 /* Block until everything enqueued by this context has finished; reports a
  * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
 int32_t mip_wait(MipContext* ctx);

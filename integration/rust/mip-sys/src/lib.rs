@@ -108,6 +108,11 @@ extern "C" {
     /// Shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, light-major, into device memory.
     pub fn mip_light_draw_lists(ctx: *mut MipContext, light_pos_xyz: *const f32, n_lights: u32, first_instance_base: u32,
                                 out_cmds: *mut c_void, async_: i32) -> i32;
+    /// Extension (not a reference behaviour): skinned instances, see the header.
+    pub fn mip_set_skeleton(ctx: *mut MipContext, parent: *const i32, inverse_bind: *const f32, joint_box: *const f32,
+                            n_joints: u32) -> i32;
+    pub fn mip_set_poses(ctx: *mut MipContext, joint_trs: *const c_void, n: u32, device: i32) -> i32;
+    pub fn mip_run_skinned(ctx: *mut MipContext, frame: *const MipFrame, out: *const MipOutputs, palette: *mut c_void) -> i32;
     pub fn mip_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn mip_comm_init(ctx: *mut MipContext, id: *const u8, rank: u32, world: u32) -> i32;
     pub fn mip_comm_destroy(ctx: *mut MipContext) -> i32;

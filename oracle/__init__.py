@@ -20,4 +20,5 @@ from .oracle import (  # noqa: F401
     cull_all_triangles,
     tlas_instances,
     light_draw_lists,
+    run_skinned,
 )

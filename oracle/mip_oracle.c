@@ -614,3 +614,157 @@ void orc_light_draw_lists(uint32_t n, const float* pos_xyz, const uint32_t* mesh
       c->firstInstance = first_instance_base + i;
     }
 }
+
+/* ---- Extension: skinned instances (BASELINE config 5). NOT a reference behaviour: the reference
+ * has no skins (top table). Specified from glTF 2.0 section 3.7.3; this
+ * restatement is the only authority for it, so parity here is against the build's own oracle. ---- */
+
+/* Affine 3x4, column-major a[c*3 + r]. Per column: (a0*b0c + a1*b1c) + a2*b2c, translation column "+ a3". */
+void orc_affine_mul(const float a[12], const float b[12], float out[12]) {
+  float o[12];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 3; ++r) {
+      float v = a[0 * 3 + r] * b[c * 3 + 0] + a[1 * 3 + r] * b[c * 3 + 1] + a[2 * 3 + r] * b[c * 3 + 2];
+      if (c == 3) v = v + a[9 + r];
+      o[c * 3 + r] = v;
+    }
+  memcpy(out, o, sizeof o);
+}
+
+/* L = T(t) * R(q) * S(s) for one joint; trs = t xyz, q ijkw, s xyz. R as UnitQuaternion::to_rotation_matrix. */
+void orc_joint_local(const float trs[10], float l[12]) {
+  float rh[16];
+  orc_quat_to_homogeneous(&trs[3], rh);
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) l[c * 3 + r] = rh[c * 4 + r] * trs[7 + c];
+  l[9] = trs[0];
+  l[10] = trs[1];
+  l[11] = trs[2];
+}
+
+typedef struct SkinJob {
+  uint32_t begin, end, n_joints;
+  const float *pos_xyz, *rot_ijkw, *scale, *inverse_bind, *joint_box, *poses, *planes;
+  const int32_t* parent;
+  float *palette, *world_aabb;
+  uint8_t* culled;
+} SkinJob;
+
+static void* skin_range(void* arg) {
+  const SkinJob* j = (const SkinJob*)arg;
+  const uint32_t J = j->n_joints;
+  float g[32][12];
+  for (uint32_t i = j->begin; i < j->end; ++i) {
+    float m16[16], m[12];
+    orc_model_matrix(&j->pos_xyz[(size_t)i * 3], &j->rot_ijkw[(size_t)i * 4], j->scale[i], m16);
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) m[c * 3 + r] = m16[c * 4 + r];
+    float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+    float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+    for (uint32_t k = 0; k < J; ++k) {
+      float l[12], ibm[12], jm[12], w[12];
+      orc_joint_local(&j->poses[((size_t)i * J + k) * 10], l);
+      if (j->parent[k] < 0) memcpy(g[k], l, sizeof l);
+      else orc_affine_mul(g[j->parent[k]], l, g[k]);
+      for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 3; ++r) ibm[c * 3 + r] = j->inverse_bind[(size_t)k * 16 + c * 4 + r];
+      orc_affine_mul(g[k], ibm, jm);
+      if (j->palette) {
+        float* p = &j->palette[((size_t)i * J + k) * 16];
+        for (int c = 0; c < 4; ++c) {
+          for (int r = 0; r < 3; ++r) p[c * 4 + r] = jm[c * 3 + r];
+          p[c * 4 + 3] = c == 3 ? 1.0f : 0.0f;
+        }
+      }
+      const float* b = &j->joint_box[(size_t)k * 6];
+      if (b[0] > b[3] || b[1] > b[4] || b[2] > b[5]) continue; /* the joint binds no vertex */
+      orc_affine_mul(m, jm, w);
+      for (int c = 0; c < 8; ++c) { /* corner order of src/ecs.rs:149-160 */
+        const float x = b[(c & 1) ? 3 : 0], z = b[(c & 2) ? 5 : 2], y = b[(c & 4) ? 4 : 1];
+        for (int r = 0; r < 3; ++r) {
+          const float v = w[0 * 3 + r] * x + w[1 * 3 + r] * y + w[2 * 3 + r] * z + w[9 + r];
+          lo[r] = rust_min(lo[r], v);
+          hi[r] = rust_max(hi[r], v);
+        }
+      }
+    }
+    float mins[3], maxs[3];
+    for (int a = 0; a < 3; ++a) { /* the same centre/half round trip as a rigid box, ecs.rs:175-178 */
+      const float centre = (hi[a] + lo[a]) / 2.0f;
+      const float half = (hi[a] - lo[a]) / 2.0f;
+      mins[a] = centre - half;
+      maxs[a] = centre + half;
+    }
+    j->culled[i] = (uint8_t)orc_coarse_culled(mins, maxs, j->planes);
+    if (j->world_aabb) {
+      memcpy(&j->world_aabb[(size_t)i * 6], mins, sizeof mins);
+      memcpy(&j->world_aabb[(size_t)i * 6 + 3], maxs, sizeof maxs);
+    }
+  }
+  return NULL;
+}
+
+int orc_skinned_bounds(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, uint32_t n_joints,
+                       const int32_t* parent, const float* inverse_bind, const float* joint_box, const float* poses,
+                       const float planes[24], float* palette, float* world_aabb, uint8_t* culled, uint32_t threads) {
+  if (n_joints == 0 || n_joints > 32) return -1;
+  for (uint32_t k = 0; k < n_joints; ++k)
+    if (parent[k] >= (int32_t)k || parent[k] < -1) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  SkinJob jobs[64];
+  pthread_t tids[64];
+  const uint32_t per = (n + threads - 1) / threads;
+  for (uint32_t t = 0; t < threads; ++t) {
+    SkinJob* j = &jobs[t];
+    j->begin = t * per < n ? t * per : n;
+    j->end = (t + 1) * per < n ? (t + 1) * per : n;
+    j->n_joints = n_joints;
+    j->pos_xyz = pos_xyz; j->rot_ijkw = rot_ijkw; j->scale = scale;
+    j->inverse_bind = inverse_bind; j->joint_box = joint_box; j->poses = poses; j->planes = planes;
+    j->parent = parent; j->palette = palette; j->world_aabb = world_aabb; j->culled = culled;
+  }
+  for (uint32_t t = 1; t < threads; ++t)
+    if (pthread_create(&tids[t], NULL, skin_range, &jobs[t]) != 0) return -1;
+  skin_range(&jobs[0]);
+  for (uint32_t t = 1; t < threads; ++t) pthread_join(tids[t], NULL);
+  return 0;
+}
+
+/* The frame of skinned instances: model matrices as always, CoarseCulled and world_aabb from the
+ * skinned bounds, then bitmap, emission and compaction unchanged. */
+int orc_run_skinned(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, const uint32_t* mesh_id,
+                    const OrcMesh* meshes, uint32_t m, uint32_t n_joints, const int32_t* parent, const float* inverse_bind,
+                    const float* joint_box, const float* poses, const float planes[24], const float cam_pos[3],
+                    uint32_t first_instance_base, uint32_t first_index_base, OrcOutputs* out, float* palette,
+                    uint32_t threads) {
+  if (check_mesh_ids(n, mesh_id, m)) return -1;
+  uint8_t* culled = out->coarse_culled;
+  uint8_t* culled_owned = NULL;
+  if (!culled) {
+    culled = culled_owned = (uint8_t*)malloc(n ? n : 1);
+    if (!culled) return -1;
+  }
+  if (out->model)
+    for (uint32_t i = 0; i < n; ++i)
+      orc_model_matrix(&pos_xyz[(size_t)i * 3], &rot_ijkw[(size_t)i * 4], scale[i], &out->model[(size_t)i * 16]);
+  int rc = orc_skinned_bounds(n, pos_xyz, rot_ijkw, scale, n_joints, parent, inverse_bind, joint_box, poses, planes,
+                              palette, out->world_aabb, culled, threads);
+  if (rc == 0) {
+    if (out->visible_bitmap) pack_bitmap(n, culled, out->visible_bitmap);
+    out->draw_count = 0;
+    out->draw_index_total = 0;
+    if (out->draw_cmds) {
+      OrcDrawCmd* sparse = (OrcDrawCmd*)malloc((size_t)(n ? n : 1) * sizeof(OrcDrawCmd));
+      if (!sparse) rc = -1;
+      else {
+        out->draw_index_total = orc_emit_draw_commands(n, pos_xyz, mesh_id, culled, meshes, cam_pos, first_instance_base,
+                                                       first_index_base, sparse);
+        out->draw_count = orc_compact_draw_stream(sparse, n, out->draw_cmds);
+        free(sparse);
+      }
+    }
+  }
+  free(culled_owned);
+  return rc;
+}

@@ -73,6 +73,7 @@ def lib():
         _lib.orc_compact_draw_stream.restype = C.c_uint32
         _lib.orc_merge_draw_lists.restype = C.c_uint32
         _lib.orc_cull_all_triangles.restype = C.c_uint32
+        _lib.orc_run_skinned.restype = C.c_int
     return _lib
 
 
@@ -232,6 +233,58 @@ def run(pos_xyz, rot_ijkw, scale, mesh_id, meshes, planes, cam_pos, first_instan
         rc = lib().orc_run_mt(*args, C.c_uint32(int(threads)))
     if rc != 0:
         raise ValueError("oracle: mesh id out of range or allocation failure")
+    res["draw_count"] = int(o.draw_count)
+    res["draw_index_total"] = int(o.draw_index_total)
+    if cmds is not None:
+        res["draw_cmds"] = cmds[: o.draw_count].copy()
+    return res
+
+
+def run_skinned(pos_xyz, rot_ijkw, scale, mesh_id, meshes, skeleton, poses, planes, cam_pos, first_instance_base=0,
+                first_index_base=0, threads=8, want=("model", "world_aabb", "visible_bitmap", "coarse_culled",
+                                                     "draw_cmds", "palette")):
+    """Extension (BASELINE config 5, no reference semantics): the frame of skinned instances.
+    skeleton = dict(parent int32[J], inverse_bind f32[J,16], joint_box f32[J,6]); poses f32[n,J,10]."""
+    pos_xyz = _f32(pos_xyz).reshape(-1, 3)
+    n = pos_xyz.shape[0]
+    rot_ijkw = _f32(rot_ijkw).reshape(-1, 4)
+    scale = _f32(scale).reshape(-1)
+    mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32).reshape(-1)
+    meshes = np.ascontiguousarray(meshes, dtype=ORC_MESH_DTYPE).reshape(-1)
+    parent = np.ascontiguousarray(skeleton["parent"], dtype=np.int32)
+    n_joints = len(parent)
+    ibm = _f32(skeleton["inverse_bind"]).reshape(n_joints, 16)
+    box = _f32(skeleton["joint_box"]).reshape(n_joints, 6)
+    poses = _f32(poses).reshape(n, n_joints, 10)
+    planes = _f32(planes, (24,))
+    cam_pos = _f32(cam_pos, (3,))
+    res = {}
+    o = _Outputs()
+    if "model" in want:
+        res["model"] = np.empty((n, 16), np.float32)
+        o.model = res["model"].ctypes.data
+    if "world_aabb" in want:
+        res["world_aabb"] = np.empty((n, 6), np.float32)
+        o.world_aabb = res["world_aabb"].ctypes.data
+    if "visible_bitmap" in want:
+        res["visible_bitmap"] = np.zeros((n + 31) // 32, np.uint32)
+        o.visible_bitmap = res["visible_bitmap"].ctypes.data
+    if "coarse_culled" in want:
+        res["coarse_culled"] = np.empty(n, np.uint8)
+        o.coarse_culled = res["coarse_culled"].ctypes.data
+    cmds = None
+    if "draw_cmds" in want:
+        cmds = np.zeros(max(n, 1), DRAW_CMD_DTYPE)
+        o.draw_cmds = cmds.ctypes.data
+    palette = None
+    if "palette" in want:
+        palette = res["palette"] = np.empty((n, n_joints, 16), np.float32)
+    rc = lib().orc_run_skinned(C.c_uint32(n), _p(pos_xyz), _p(rot_ijkw), _p(scale), _p(mesh_id), _p(meshes),
+                               C.c_uint32(len(meshes)), C.c_uint32(n_joints), _p(parent), _p(ibm), _p(box), _p(poses),
+                               _p(planes), _p(cam_pos), C.c_uint32(first_instance_base), C.c_uint32(first_index_base),
+                               C.byref(o), _p(palette) if palette is not None else None, C.c_uint32(int(threads)))
+    if rc != 0:
+        raise ValueError("oracle: bad skeleton, mesh id out of range or allocation failure")
     res["draw_count"] = int(o.draw_count)
     res["draw_index_total"] = int(o.draw_index_total)
     if cmds is not None:

@@ -79,6 +79,7 @@ struct KernelArgs {
   float* world_aabb;            // n*6 or null
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
+  const uint8_t* culled_override;  // n or null: CoarseCulled decided by an earlier kernel (skinned instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
@@ -182,14 +183,18 @@ __device__ __forceinline__ void finish_aabb(const float (&lo)[3], const float (&
 // with a 0 or 1 entry of T, S and the homogeneous row/column is exact, (T·R)·S collapses
 // to M[r][c] = fl(R[r][c]·s), M[:,3] = (p,1), M[3,:] = (0,0,0,1), and w = 1 for every
 // corner, so `/ w` is the identity.
-__device__ __forceinline__ void instance_fast(const float (&r)[3][3], float px, float py, float pz,
-                                              float s, const MeshEntry& mb, Instance& o) {
+__device__ __forceinline__ void model_fast(const float (&r)[3][3], float px, float py, float pz, float s, Instance& o) {
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) o.m[c * 3 + rr] = r[rr][c] * s;
   o.m[9] = px; o.m[10] = py; o.m[11] = pz;
   o.row3 = 0;
+}
+
+__device__ __forceinline__ void instance_fast(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+  model_fast(r, px, py, pz, s, o);
   float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
   float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
   const float bx[2] = {mb.min_x, mb.max_x}, by[2] = {mb.min_y, mb.max_y}, bz[2] = {mb.min_z, mb.max_z};
@@ -231,13 +236,13 @@ __device__ __forceinline__ void gemm4(const float (&a)[16], const float (&b)[16]
 // rot.to_homogeneous() * scaling(s) as two full 4x4 products, full mat4*vec4 per corner
 // and the divide by w — so non-finite inputs poison exactly the entries they poison in
 // the reference. Taken by a whole wave when any of its lanes fails the finite test.
-__device__ __forceinline__ void instance_general(const float (&r)[3][3], float px, float py, float pz,
-                                              float s, const MeshEntry& mb, Instance& o) {
+__device__ __forceinline__ void model_general(const float (&r)[3][3], float px, float py, float pz, float s, Instance& o,
+                                              float (&m)[16]) {
   float t[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, px, py, pz, 1};
   float rh[16] = {r[0][0], r[1][0], r[2][0], 0, r[0][1], r[1][1], r[2][1], 0,
                   r[0][2], r[1][2], r[2][2], 0, 0, 0, 0, 1};
   float sc[16] = {s, 0, 0, 0, 0, s, 0, 0, 0, 0, s, 0, 0, 0, 0, 1};
-  float tr[16], m[16];
+  float tr[16];
   gemm4(t, rh, tr);
   gemm4(tr, sc, m);
 #pragma unroll
@@ -247,6 +252,12 @@ __device__ __forceinline__ void instance_general(const float (&r)[3][3], float p
   o.row3 = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) o.row3 |= (m[c * 4 + 3] != m[c * 4 + 3]) ? (1u << c) : 0u;
+}
+
+__device__ __forceinline__ void instance_general(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+  float m[16];
+  model_general(r, px, py, pz, s, o, m);
   float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
   float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
 #pragma unroll
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
 
   MIP_STAMP(1);
   // ---- frustum test, LOD, command length ----
-  const bool culled = coarse_culled(inst, a.planes);
+  const bool culled = a.culled_override ? a.culled_override[il] != 0 : coarse_culled(inst, a.planes);
   const bool visible = active && !culled;
   const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
   const float dist_sq = dx * dx + dy * dy + dz * dz;
@@ -1002,6 +1013,188 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
     } else {
       for (uint32_t w = tid; w < words; w += kTile) dst[w] = row[w];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Extension (BASELINE config 5): skinned instances — joint palette + bounds of the posed mesh
+// ---------------------------------------------------------------------------------------
+// The reference has no skinning: this is specified from glTF 2.0
+// (section 3.7.3, skins) and checked against this repository's oracle only (orc_skinned_bounds).
+//   L_k = T(t_k) * R(q_k) * S(s_k)           the animated LOCAL transform of joint k
+//   G_k = G_parent(k) * L_k                  (roots: G_k = L_k; parents precede children)
+//   J_k = G_k * inverseBind_k                the palette entry the vertex shader blends
+//   box = union over k of (M * J_k) * joint_box_k      (M = the instance's model matrix)
+// A skinned vertex is a convex combination of J_k * v over the joints that influence it, so the
+// union of the transformed per-joint bind-pose boxes bounds the posed mesh. All matrices are
+// affine 3x4 (column-major, a[c*3 + r]); a product is, per column c, the column axpys
+// (a0*b0c + a1*b1c) + a2*b2c, plus "+ a3" for the translation column — no FMA, this order.
+// The box then goes through the same centre/half round trip and plane test as a rigid instance
+// (rows a-2, a-3), and the byte written here replaces coarse_culled() in the instance kernel
+// (KernelArgs.culled_override), which emits matrices, bitmap and commands as for any frame.
+//
+// Mapping: one lane per (instance, joint). A wave holds floor(64 / J) instances; the parent's
+// matrix comes from the parent's lane (ds_bpermute), one round per hierarchy level. Poses are
+// read and palettes written through LDS so that every global access is lane-contiguous
+// (J*40 B in, J*64 B out per instance). HBM-bound: 40 B read + 64 B written per joint.
+constexpr uint32_t kMaxJoints = 32;
+constexpr uint32_t kPoseWords = 10;  // t xyz, q ijkw, s xyz
+
+struct alignas(16) JointEntry {
+  float ibm[12];     // rows 0..2 of inverseBindMatrices[k], column-major 3x4
+  float box[6];      // min xyz, max xyz of the bind-pose vertices weighted to this joint; min > max: none
+  int32_t parent;    // < k, or -1
+  uint32_t depth;    // 0 for roots
+};
+static_assert(sizeof(JointEntry) == 80, "JointEntry layout");
+
+struct SkinArgs {
+  const float* pos;            // n*3
+  const float4* rot;           // n
+  const float* scale;          // n
+  const float* poses;          // n * J * 10
+  const JointEntry* joints;    // J
+  float4* palette;             // n * J * 4 (mat4 column-major) or null
+  float* world_aabb;           // n*6 or null
+  uint8_t* culled;             // n
+  uint32_t n;
+  uint32_t n_joints;
+  uint32_t max_depth;
+  float planes[24];
+};
+
+__device__ __forceinline__ void affine_mul(const float (&a)[12], const float (&b)[12], float (&o)[12]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float v = a[0 * 3 + r] * b[c * 3 + 0] + a[1 * 3 + r] * b[c * 3 + 1] + a[2 * 3 + r] * b[c * 3 + 2];
+      if (c == 3) v = v + a[9 + r];
+      o[c * 3 + r] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_io[4][64 * 16];  // per wave: poses in (<= 640 words), palette out (<= 1024)
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t J = a.n_joints;
+  const uint32_t ipw = 64u / J;                       // instances per wave
+  const uint32_t wave_first = (blockIdx.x * 4u + wave) * ipw;
+  if (wave_first >= a.n) return;                      // whole wave idle (no block-level barriers below)
+  const uint32_t in_wave = a.n - wave_first < ipw ? a.n - wave_first : ipw;
+  const uint32_t g = lane / J, joint = lane - g * J;
+  const bool valid = g < in_wave;
+  const uint32_t inst = wave_first + (valid ? g : 0u);
+  float* io = s_io[wave];
+
+  // ---- poses: the wave's in_wave*J*10 words are contiguous ----
+  {
+    const float* src = a.poses + (size_t)wave_first * J * kPoseWords;
+    const uint32_t words = in_wave * J * kPoseWords;
+    for (uint32_t w = lane; w < words; w += 64u) io[w] = src[w];
+  }
+  // instance columns (the J lanes of an instance read the same 36 B)
+  const float px = a.pos[3 * (size_t)inst + 0], py = a.pos[3 * (size_t)inst + 1], pz = a.pos[3 * (size_t)inst + 2];
+  const float4 q = a.rot[inst];
+  const float sc = a.scale[inst];
+  const JointEntry je = a.joints[valid ? joint : 0u];
+
+  // ---- model matrix exactly as the instance kernel builds it ----
+  float r[3][3];
+  quat_to_rotation(q.x, q.y, q.z, q.w, r);
+  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  Instance mi;
+  if (__builtin_expect(__any(!(mag < 3.0e38f)), 0)) {
+    float m16[16];
+    model_general(r, px, py, pz, sc, mi, m16);
+  } else {
+    model_fast(r, px, py, pz, sc, mi);
+  }
+
+  // ---- local transform ----
+  __builtin_amdgcn_wave_barrier();
+  float t[kPoseWords];
+#pragma unroll
+  for (uint32_t k = 0; k < kPoseWords; ++k) t[k] = io[(valid ? lane : 0u) * kPoseWords + k];
+  float lr[3][3];
+  quat_to_rotation(t[3], t[4], t[5], t[6], lr);
+  float G[12];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) G[c * 3 + rr] = lr[rr][c] * t[7 + c];
+  G[9] = t[0]; G[10] = t[1]; G[11] = t[2];
+  float L[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) L[k] = G[k];
+
+  // ---- hierarchy: one round per level, parents sit in lower lanes of the same instance ----
+  const int parent_lane = (int)(lane - joint) + (je.parent < 0 ? (int)joint : je.parent);
+  for (uint32_t d = 1; d <= a.max_depth; ++d) {
+    float P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      P[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(parent_lane << 2, __float_as_int(G[k])));
+    if (je.depth == d) affine_mul(P, L, G);
+  }
+
+  // ---- palette entry and this joint's share of the bounds ----
+  float Jm[12];
+  affine_mul(G, je.ibm, Jm);
+  float W[12];
+  affine_mul(mi.m, Jm, W);
+  float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+  const bool has_box = valid && !(je.box[0] > je.box[3] || je.box[1] > je.box[4] || je.box[2] > je.box[5]);
+  if (has_box) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {  // corner order of src/ecs.rs:149-160
+      const float x = je.box[(c & 1) ? 3 : 0], z = je.box[(c & 2) ? 5 : 2], y = je.box[(c & 4) ? 4 : 1];
+      float v[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) v[rr] = W[0 * 3 + rr] * x + W[1 * 3 + rr] * y + W[2 * 3 + rr] * z + W[9 + rr];
+      fold_corner(v, lo, hi);
+    }
+  }
+  // fold over the instance's joints: min/max ignore NaN and are order-independent otherwise
+  for (uint32_t step = 1; step < J; step <<= 1) {
+    const bool take = joint + step < J;
+    const int from = (int)(take ? lane + step : lane) << 2;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ol = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(lo[k])));
+      const float oh = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(hi[k])));
+      lo[k] = fminf(lo[k], ol);
+      hi[k] = fmaxf(hi[k], oh);
+    }
+  }
+  if (valid && joint == 0u) {
+    finish_aabb(lo, hi, mi);
+    a.culled[inst] = coarse_culled(mi, a.planes) ? 1 : 0;
+    if (a.world_aabb) {
+      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)inst * 6);
+      o2[0] = make_float2(mi.mins[0], mi.mins[1]);
+      o2[1] = make_float2(mi.mins[2], mi.maxs[0]);
+      o2[2] = make_float2(mi.maxs[1], mi.maxs[2]);
+    }
+  }
+
+  // ---- palette: mat4 per joint, staged so that each store instruction is 1 KiB contiguous ----
+  if (a.palette) {
+    __builtin_amdgcn_wave_barrier();  // every lane has read its pose words
+    float4* st = reinterpret_cast<float4*>(io) + lane * 4u;
+    st[0] = make_float4(Jm[0], Jm[1], Jm[2], 0.0f);
+    st[1] = make_float4(Jm[3], Jm[4], Jm[5], 0.0f);
+    st[2] = make_float4(Jm[6], Jm[7], Jm[8], 0.0f);
+    st[3] = make_float4(Jm[9], Jm[10], Jm[11], 1.0f);
+    __builtin_amdgcn_wave_barrier();
+    float4* out = a.palette + (size_t)wave_first * J * 4u;
+    const uint32_t quads = in_wave * J * 4u;
+    for (uint32_t w = lane; w < quads; w += 64u) out[w] = reinterpret_cast<const float4*>(io)[w];
   }
 }
 

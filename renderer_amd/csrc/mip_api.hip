@@ -76,6 +76,13 @@ struct MipContext {
   uint32_t* d_indices = nullptr;
   uint32_t n_vertices = 0, n_indices = 0;
   bool have_geometry = false;
+  // skinned extension (mip_set_skeleton / mip_set_poses / mip_run_skinned)
+  mip::JointEntry* d_joints = nullptr;
+  uint32_t n_joints = 0, max_joint_depth = 0;
+  float* d_poses_owned = nullptr;
+  const float* d_poses = nullptr;  // owned copy or a borrowed device pointer
+  uint32_t poses_n = 0;
+  uint8_t* d_skin_culled = nullptr;  // per instance CoarseCulled of the skinned box
   int cu_count = 0;
   // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
@@ -283,6 +290,9 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_blas);
   (void)hipFree(ctx->d_vertices);
   (void)hipFree(ctx->d_indices);
+  (void)hipFree(ctx->d_joints);
+  (void)hipFree(ctx->d_poses_owned);
+  (void)hipFree(ctx->d_skin_culled);
   for (auto& sl : ctx->slots) {
     (void)hipFree(sl.d_status);
     (void)hipFree(sl.d_scalars);
@@ -514,8 +524,7 @@ int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const voi
   return set_instances_common(ctx, pos_xyz, rot_ijkw, scale, mesh_id, n, hipMemcpyDeviceToDevice);
 }
 
-int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
-  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, bool skinned, void* palette) {
   if (int32_t rc = validate_run(ctx, frame, out)) return rc;
   const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
   const bool async = device_out && (out->flags & MIP_OUT_ASYNC) != 0;
@@ -546,6 +555,12 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     a.draw_count = sl.d_scalars + 2;
     a.src_index_offset = sl.d_tmp_src;
   }
+  if (skinned) {
+    // the skinned box decides CoarseCulled (and is what world_aabb reports); launched first, same stream
+    a.culled_override = ctx->d_skin_culled;
+    a.world_aabb = nullptr;
+  }
+
   // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh tag per launch marks
   // the level-0 words; the level-1 accumulators alternate between two buffers by tag parity,
   // the kernel zeroing the other one. Launches without draw commands do not touch the state.
@@ -564,6 +579,22 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
     if (a.index_total) MIP_HIP(ctx, hipMemsetAsync(a.index_total, 0, 4, stream));
   } else {
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, stream));
+    if (skinned) {
+      mip::SkinArgs k{};
+      k.pos = ctx->d_pos; k.rot = ctx->d_rot; k.scale = ctx->d_scale;
+      k.poses = ctx->d_poses;
+      k.joints = ctx->d_joints;
+      k.palette = (float4*)palette;
+      k.world_aabb = (float*)out->world_aabb;
+      k.culled = ctx->d_skin_culled;
+      k.n = n;
+      k.n_joints = ctx->n_joints;
+      k.max_depth = ctx->max_joint_depth;
+      std::memcpy(k.planes, frame->planes, sizeof k.planes);
+      const uint32_t per_block = 4u * (64u / ctx->n_joints);
+      hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(256), 0, stream, k);
+      MIP_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, stream, a);
     MIP_HIP(ctx, hipGetLastError());
     if (triangles) {
@@ -770,6 +801,76 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
   for (uint32_t k = done; k < steps; ++k)
     if (int32_t rc = mip_run(ctx, frame, &outputs[k % n_outputs])) return rc;
   return MIP_OK;
+}
+
+int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  return run_frame(ctx, frame, out, false, nullptr);
+}
+
+int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* inverse_bind, const float* joint_box,
+                         uint32_t n_joints) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!parent || !inverse_bind || !joint_box) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL skeleton array");
+  static_assert(MIP_MAX_JOINTS == mip::kMaxJoints && MIP_POSE_FLOATS == mip::kPoseWords, "skinning limits");
+  if (n_joints == 0 || n_joints > MIP_MAX_JOINTS)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_joints %u outside 1..%u", n_joints, (unsigned)MIP_MAX_JOINTS);
+  std::vector<mip::JointEntry> joints(n_joints);
+  uint32_t max_depth = 0;
+  for (uint32_t k = 0; k < n_joints; ++k) {
+    if (parent[k] >= (int32_t)k || parent[k] < -1)
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "joint %u: parent %d must be -1 or an earlier joint", k, parent[k]);
+    mip::JointEntry& j = joints[k];
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) j.ibm[c * 3 + r] = inverse_bind[(size_t)k * 16 + c * 4 + r];
+    std::memcpy(j.box, joint_box + (size_t)k * 6, sizeof j.box);
+    j.parent = parent[k];
+    j.depth = parent[k] < 0 ? 0u : joints[parent[k]].depth + 1u;
+    if (j.depth > max_depth) max_depth = j.depth;
+  }
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  if (!ctx->d_joints) MIP_HIP(ctx, hipMalloc(&ctx->d_joints, sizeof(mip::JointEntry) * MIP_MAX_JOINTS));
+  MIP_HIP(ctx, hipMemcpy(ctx->d_joints, joints.data(), sizeof(mip::JointEntry) * n_joints, hipMemcpyHostToDevice));
+  if (n_joints != ctx->n_joints) {  // the pose layout depends on the joint count
+    ctx->d_poses = nullptr;
+    ctx->poses_n = 0;
+  }
+  ctx->n_joints = n_joints;
+  ctx->max_joint_depth = max_depth;
+  return MIP_OK;
+}
+
+int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_t device) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!ctx->n_joints) return fail(ctx, MIP_ERR_NOT_READY, "set the skeleton before the poses");
+  if (!ctx->have_instances || n != ctx->n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u poses for %u instances", n, ctx->n);
+  if (!joint_trs && n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "joint_trs is NULL");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  if (device) {
+    ctx->d_poses = (const float*)joint_trs;
+  } else {
+    if (!ctx->d_poses_owned)
+      MIP_HIP(ctx, hipMalloc(&ctx->d_poses_owned, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * MIP_MAX_JOINTS * MIP_POSE_FLOATS * 4));
+    if (n)
+      MIP_HIP(ctx, hipMemcpy(ctx->d_poses_owned, joint_trs, (size_t)n * ctx->n_joints * MIP_POSE_FLOATS * 4, hipMemcpyHostToDevice));
+    ctx->d_poses = ctx->d_poses_owned;
+  }
+  ctx->poses_n = n;
+  return MIP_OK;
+}
+
+int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, void* palette) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out is NULL");
+  if (!(out->flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_skinned needs MIP_OUT_DEVICE outputs");
+  if (out->culled_index_buffer) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "the per-triangle stage does not skin vertices");
+  if (!ctx->n_joints || ctx->poses_n != ctx->n || (ctx->n && !ctx->d_poses))
+    return fail(ctx, MIP_ERR_NOT_READY, "skeleton or poses not set for the resident instances");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (!ctx->d_skin_culled) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_culled, ctx->max_instances ? ctx->max_instances : 1));
+  return run_frame(ctx, frame, out, true, palette);
 }
 
 int32_t mip_light_draw_lists(MipContext* ctx, const float* light_pos_xyz, uint32_t n_lights, uint32_t first_instance_base,

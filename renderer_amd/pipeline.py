@@ -260,6 +260,32 @@ class InstancePipeline:
                                                    int(chunk_stride_bytes), out_cmds_ptr,
                                                    out_count_ptr, 1 if async_ else 0))
 
+    # -- extension: skinned instances (BASELINE config 5; not a reference behaviour) --
+    def set_skeleton(self, parent, inverse_bind, joint_box):
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        j = len(parent)
+        ibm = np.ascontiguousarray(inverse_bind, dtype=np.float32).reshape(j, 16)
+        box = np.ascontiguousarray(joint_box, dtype=np.float32).reshape(j, 6)
+        self._check(self._lib.mip_set_skeleton(self._ctx, parent.ctypes.data, ibm.ctypes.data, box.ctypes.data, j))
+        self._n_joints = j
+
+    def set_poses(self, joint_trs):
+        """Host array n x J x 10 (t xyz, q ijkw, s xyz per joint); copied."""
+        poses = np.ascontiguousarray(joint_trs, dtype=np.float32)
+        n = poses.size // (max(getattr(self, "_n_joints", 0), 1) * 10)
+        self._check(self._lib.mip_set_poses(self._ctx, poses.ctypes.data, n, 0))
+
+    def set_poses_device(self, ptr, n):
+        """Borrow a device buffer of n x J x 10 floats (not copied)."""
+        self._check(self._lib.mip_set_poses(self._ctx, ptr, int(n), 1))
+
+    def run_skinned(self, frame, palette=0, async_=False, **outputs):
+        """One frame of skinned instances; outputs as prepare_outputs (device pointers)."""
+        out = self.prepare_outputs(async_=async_, **outputs)
+        rc = self._lib.mip_run_skinned(self._ctx, C.addressof(frame), C.addressof(out), palette or None)
+        if rc != 0:
+            self._check(rc)
+
     def light_draw_lists(self, light_pos_xyz, out_cmds_ptr, first_instance_base=0, async_=False):
         """Per-light shadow-pass draw lists (shadow_mapping.rs:405-478): n_lights x n commands, light-major,
         into device memory at out_cmds_ptr."""

@@ -19,6 +19,7 @@ CONFIGS = {
     2: dict(name="damaged_helmet_100k", n=100_000, workload="DamagedHelmet, 100 k static instances"),
     3: dict(name="mixed_1m", n=1_000_000, workload="mixed 64-mesh scene, 1 M instances"),
     4: dict(name="mixed_10m", n=10_000_000, workload="mixed 64-mesh scene, 10 M instances (8 shards)"),
+    5: dict(name="rigged_figure_256k", n=256_000, workload="RiggedFigure-like skinned figure (19 joints), 256 k animated instances"),
 }
 
 
@@ -167,6 +168,90 @@ def make_scene(config, n=None, first=0, all_visible=False):
     return dict(config=config, name=cfg["name"], workload=cfg["workload"], n=n, meshes=meshes,
                 pos=pos, rot=rot, scale=scale, mesh_id=mesh, planes=default_planes(),
                 cam_pos=np.asarray(DEFAULT_CAMERA["cam_pos"], np.float32))
+
+
+# ---- skinned extension (BASELINE config 5; the reference has no skinning) ----------------------
+
+def rigged_figure_skeleton():
+    """A 19-joint humanoid in the shape of the Khronos RiggedFigure sample (the asset is not in the
+    container: joint count 19 as BASELINE names it; positions are a stand-in). Bind pose: every joint
+    at position p_k with identity rotation, so inverse_bind_k = T(-p_k) and the bind-pose local
+    translation is p_k - p_parent. joint_box_k: the bone towards the first child, padded."""
+    names = ["hips", "spine", "chest", "neck", "head", "l_shoulder", "l_upper_arm", "l_forearm", "r_shoulder", "r_upper_arm",
+             "r_forearm", "l_thigh", "l_shin", "l_foot", "r_thigh", "r_shin", "r_foot", "l_toe", "r_toe"]
+    parent = np.array([-1, 0, 1, 2, 3, 2, 5, 6, 2, 8, 9, 0, 11, 12, 0, 14, 15, 13, 16], np.int32)
+    p = np.array([[0, 0.95, 0], [0, 1.10, 0], [0, 1.30, 0], [0, 1.50, 0], [0, 1.60, 0],
+                  [0.10, 1.45, 0], [0.22, 1.42, 0], [0.48, 1.42, 0], [-0.10, 1.45, 0], [-0.22, 1.42, 0], [-0.48, 1.42, 0],
+                  [0.10, 0.90, 0], [0.10, 0.50, 0], [0.10, 0.08, 0], [-0.10, 0.90, 0], [-0.10, 0.50, 0], [-0.10, 0.08, 0],
+                  [0.10, 0.02, 0.15], [-0.10, 0.02, 0.15]], np.float64)
+    end = p.copy()  # far end of each bone: the first child, or a short stub
+    for k in range(len(parent)):
+        kids = np.nonzero(parent == k)[0]
+        end[k] = p[kids[0]] if len(kids) else p[k] + (p[k] - p[parent[k]]) * 0.6
+    end[4] = p[4] + [0, 0.22, 0]      # head
+    end[7] = p[7] + [0.25, 0, 0]      # forearms reach the hands
+    end[10] = p[10] - [0.25, 0, 0]
+    pad = 0.07
+    box = np.concatenate([np.minimum(p, end) - pad, np.maximum(p, end) + pad], axis=1).astype(np.float32)
+    ibm = np.tile(np.eye(4, dtype=np.float32).T.reshape(16), (len(parent), 1))
+    ibm[:, 12:15] = (-p).astype(np.float32)  # column-major: translation in elements 12..14
+    local_t = p.copy()
+    local_t[1:] = p[1:] - p[parent[1:]]
+    return dict(names=names, parent=parent, inverse_bind=ibm, joint_box=box, bind_translation=local_t.astype(np.float32))
+
+
+def rigged_figure_mesh_table():
+    """One skinned mesh. Bind-pose box of the figure above; 2 LODs; index counts of the order of the
+    Khronos sample (unverified, only used as table values)."""
+    t = np.zeros(1, dtype=MESH_DTYPE)
+    t["aabb_min"] = (-0.80, -0.05, -0.15)
+    t["aabb_max"] = (0.80, 1.90, 0.30)
+    t["n_lods"] = 2
+    t["index_len"][0, :2] = (2304, 1152)
+    t["index_offset"][0, :2] = (0, 2304)
+    t["vertex_offset"] = 0
+    return t
+
+
+def make_poses(n, skeleton, seed, first=0, max_angle_deg=50.0):
+    """Per instance and joint: bind translation, a random rotation of up to max_angle_deg about a random
+    axis (4 draws), unit scale except every 7th joint slot (0.9 .. 1.1 per axis from the same draws)."""
+    j = len(skeleton["parent"])
+    poses = np.empty((n, j, 10), np.float32)
+    poses[:, :, 0:3] = skeleton["bind_translation"][None]
+    step = 1 << 16
+    for b in range(0, n, step):
+        e = min(n, b + step)
+        u = u01(splitmix64(seed, (first + b) * j * 4, (e - b) * j * 4)).reshape(e - b, j, 4)
+        z = 2.0 * u[..., 0] - 1.0
+        phi = 2.0 * np.pi * u[..., 1]
+        rxy = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+        half = np.radians(max_angle_deg) * u[..., 2] * 0.5
+        sn = np.sin(half)
+        poses[b:e, :, 3] = (rxy * np.cos(phi) * sn).astype(np.float32)
+        poses[b:e, :, 4] = (rxy * np.sin(phi) * sn).astype(np.float32)
+        poses[b:e, :, 5] = (z * sn).astype(np.float32)
+        poses[b:e, :, 6] = np.cos(half).astype(np.float32)
+        sc = np.ones((e - b, j, 3))
+        odd = (np.arange(j) % 7) == 3
+        sc[:, odd, 0] = 0.9 + 0.2 * u[:, odd, 3]
+        sc[:, odd, 1] = 1.1 - 0.2 * u[:, odd, 3]
+        sc[:, odd, 2] = 0.9 + 0.2 * u[:, odd, 0]
+        poses[b:e, :, 7:10] = sc.astype(np.float32)
+    return poses
+
+
+def make_skinned_scene(n=None, first=0):
+    """BASELINE config 5: n instances of one skinned figure, each with its own pose."""
+    cfg = CONFIGS[5]
+    n = cfg["n"] if n is None else int(n)
+    meshes = rigged_figure_mesh_table()
+    pos, rot, scale, mesh = make_instances(n, 1, SEED_BASE + 5, first=first)
+    sk = rigged_figure_skeleton()
+    poses = make_poses(n, sk, SEED_BASE + 0x500, first=first)
+    return dict(config=5, name=cfg["name"], workload=cfg["workload"], n=n, meshes=meshes, pos=pos, rot=rot, scale=scale,
+                mesh_id=mesh, planes=default_planes(), cam_pos=np.asarray(DEFAULT_CAMERA["cam_pos"], np.float32),
+                skeleton=sk, poses=poses)
 
 
 # ---- synthetic geometry for the per-triangle stage (row f-1) --------------------------------

@@ -219,6 +219,50 @@ def test_light_draw_lists_against_numpy(oracle_mod):
     assert len({int(got[l]["indexCount"].astype(np.uint64).sum()) for l in range(4)}) > 1  # the lights do differ
 
 
+def test_skinned_extension_against_float64(oracle_mod):
+    """Extension (BASELINE config 5; no reference semantics): palette and skinned boxes of the oracle
+    against an independent float64 evaluation of glTF's J_k = G_k * IBM_k, and the bind pose."""
+    from renderer_amd import scene
+
+    s = scene.make_skinned_scene(300)
+    sk, poses = s["skeleton"], s["poses"]
+    got = oracle_mod.run_skinned(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], sk, poses, s["planes"], s["cam_pos"])
+    j = len(sk["parent"])
+
+    def trs(t, q, sc):
+        i, jj, k, w = (float(x) for x in q)
+        r = np.array([[w * w + i * i - jj * jj - k * k, 2 * (i * jj - w * k), 2 * (w * jj + i * k)],
+                      [2 * (w * k + i * jj), w * w - i * i + jj * jj - k * k, 2 * (jj * k - w * i)],
+                      [2 * (i * k - w * jj), 2 * (w * i + jj * k), w * w - i * i - jj * jj + k * k]])
+        m = np.eye(4)
+        m[:3, :3] = r * np.asarray(sc, np.float64)[None, :]
+        m[:3, 3] = t
+        return m
+
+    for inst in (0, 17, 299):
+        g = [None] * j
+        lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+        model = trs(s["pos"][inst], s["rot"][inst], [s["scale"][inst]] * 3)
+        for k in range(j):
+            l = trs(poses[inst, k, 0:3], poses[inst, k, 3:7], poses[inst, k, 7:10])
+            g[k] = l if sk["parent"][k] < 0 else g[sk["parent"][k]] @ l
+            jm = g[k] @ sk["inverse_bind"][k].reshape(4, 4).T.astype(np.float64)
+            assert np.allclose(got["palette"][inst, k].reshape(4, 4).T, jm, rtol=1e-5, atol=1e-5)
+            b = sk["joint_box"][k].astype(np.float64)
+            for c in range(8):
+                v = model @ jm @ np.array([b[3 if c & 1 else 0], b[4 if c & 4 else 1], b[5 if c & 2 else 2], 1.0])
+                lo, hi = np.minimum(lo, v[:3]), np.maximum(hi, v[:3])
+        assert np.allclose(got["world_aabb"][inst], np.concatenate([lo, hi]), rtol=1e-4, atol=1e-4)
+    bind = poses[:4].copy()
+    bind[:, :, 3:6], bind[:, :, 6], bind[:, :, 7:] = 0.0, 1.0, 1.0
+    r0 = oracle_mod.run_skinned(s["pos"][:4], s["rot"][:4], s["scale"][:4], s["mesh_id"][:4], s["meshes"], sk, bind,
+                                s["planes"], s["cam_pos"])
+    assert np.abs(r0["palette"] - np.eye(4, dtype=np.float32).reshape(16)).max() < 1e-6  # bind pose: identity palette
+    with pytest.raises(ValueError):
+        oracle_mod.run_skinned(s["pos"][:4], s["rot"][:4], s["scale"][:4], s["mesh_id"][:4], s["meshes"],
+                               dict(sk, parent=np.array([0] + list(sk["parent"][1:]), np.int32)), bind, s["planes"], s["cam_pos"])
+
+
 def test_mesh_id_out_of_range_is_rejected(oracle_mod):
     from renderer_amd import scene
 
