@@ -271,12 +271,12 @@ int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_
 
 /* One frame of skinned instances. Per instance and joint
  *   L_k = T*R*S of the pose, G_k = G_parent * L_k, J_k = G_k * inverse_bind_k   (affine, fp32)
- * the palette (n x n_joints mat4, column-major, DEVICE pointer, may be NULL) receives J_k; the
- * instance's world box becomes the union over joints of (M * J_k) * joint_box_k, M being its
- * model matrix, and replaces the rigid box in the frustum test; everything else — model[],
- * bitmap, draw commands, count, TLAS rows — is produced as by mip_run (out->world_aabb receives
- * the skinned box). out must carry MIP_OUT_DEVICE; culled_index_buffer is not supported (the
- * per-triangle stage does not skin vertices). */
+ * the palette (n x n_joints mat4, column-major, DEVICE pointer, may be NULL) receives J_k. The
+ * union over joints of J_k * joint_box_k (8 corners each) is the instance's posed box in mesh
+ * space; it takes the place of the mesh table's aabb for that instance, and everything else —
+ * model[], world box, frustum test, bitmap, draw commands, count, TLAS rows — is produced from
+ * it exactly as mip_run does from GltfMesh.aabb. out must carry MIP_OUT_DEVICE;
+ * culled_index_buffer is not supported (the per-triangle stage does not skin vertices). */
 int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, void* palette);
 
 /* Block until everything enqueued by this context has finished; reports a

@@ -644,10 +644,9 @@ void orc_joint_local(const float trs[10], float l[12]) {
 
 typedef struct SkinJob {
   uint32_t begin, end, n_joints;
-  const float *pos_xyz, *rot_ijkw, *scale, *inverse_bind, *joint_box, *poses, *planes;
+  const float *inverse_bind, *joint_box, *poses;
   const int32_t* parent;
-  float *palette, *world_aabb;
-  uint8_t* culled;
+  float *palette, *local_box;
 } SkinJob;
 
 static void* skin_range(void* arg) {
@@ -655,14 +654,10 @@ static void* skin_range(void* arg) {
   const uint32_t J = j->n_joints;
   float g[32][12];
   for (uint32_t i = j->begin; i < j->end; ++i) {
-    float m16[16], m[12];
-    orc_model_matrix(&j->pos_xyz[(size_t)i * 3], &j->rot_ijkw[(size_t)i * 4], j->scale[i], m16);
-    for (int c = 0; c < 4; ++c)
-      for (int r = 0; r < 3; ++r) m[c * 3 + r] = m16[c * 4 + r];
     float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
     float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
     for (uint32_t k = 0; k < J; ++k) {
-      float l[12], ibm[12], jm[12], w[12];
+      float l[12], ibm[12], jm[12];
       orc_joint_local(&j->poses[((size_t)i * J + k) * 10], l);
       if (j->parent[k] < 0) memcpy(g[k], l, sizeof l);
       else orc_affine_mul(g[j->parent[k]], l, g[k]);
@@ -678,35 +673,23 @@ static void* skin_range(void* arg) {
       }
       const float* b = &j->joint_box[(size_t)k * 6];
       if (b[0] > b[3] || b[1] > b[4] || b[2] > b[5]) continue; /* the joint binds no vertex */
-      orc_affine_mul(m, jm, w);
       for (int c = 0; c < 8; ++c) { /* corner order of src/ecs.rs:149-160 */
         const float x = b[(c & 1) ? 3 : 0], z = b[(c & 2) ? 5 : 2], y = b[(c & 4) ? 4 : 1];
         for (int r = 0; r < 3; ++r) {
-          const float v = w[0 * 3 + r] * x + w[1 * 3 + r] * y + w[2 * 3 + r] * z + w[9 + r];
+          const float v = jm[0 * 3 + r] * x + jm[1 * 3 + r] * y + jm[2 * 3 + r] * z + jm[9 + r];
           lo[r] = rust_min(lo[r], v);
           hi[r] = rust_max(hi[r], v);
         }
       }
     }
-    float mins[3], maxs[3];
-    for (int a = 0; a < 3; ++a) { /* the same centre/half round trip as a rigid box, ecs.rs:175-178 */
-      const float centre = (hi[a] + lo[a]) / 2.0f;
-      const float half = (hi[a] - lo[a]) / 2.0f;
-      mins[a] = centre - half;
-      maxs[a] = centre + half;
-    }
-    j->culled[i] = (uint8_t)orc_coarse_culled(mins, maxs, j->planes);
-    if (j->world_aabb) {
-      memcpy(&j->world_aabb[(size_t)i * 6], mins, sizeof mins);
-      memcpy(&j->world_aabb[(size_t)i * 6 + 3], maxs, sizeof maxs);
-    }
+    memcpy(&j->local_box[(size_t)i * 6], lo, sizeof lo);
+    memcpy(&j->local_box[(size_t)i * 6 + 3], hi, sizeof hi);
   }
   return NULL;
 }
 
-int orc_skinned_bounds(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, uint32_t n_joints,
-                       const int32_t* parent, const float* inverse_bind, const float* joint_box, const float* poses,
-                       const float planes[24], float* palette, float* world_aabb, uint8_t* culled, uint32_t threads) {
+int orc_skinned_bounds(uint32_t n, uint32_t n_joints, const int32_t* parent, const float* inverse_bind,
+                       const float* joint_box, const float* poses, float* palette, float* local_box, uint32_t threads) {
   if (n_joints == 0 || n_joints > 32) return -1;
   for (uint32_t k = 0; k < n_joints; ++k)
     if (parent[k] >= (int32_t)k || parent[k] < -1) return -1;
@@ -720,9 +703,8 @@ int orc_skinned_bounds(uint32_t n, const float* pos_xyz, const float* rot_ijkw, 
     j->begin = t * per < n ? t * per : n;
     j->end = (t + 1) * per < n ? (t + 1) * per : n;
     j->n_joints = n_joints;
-    j->pos_xyz = pos_xyz; j->rot_ijkw = rot_ijkw; j->scale = scale;
-    j->inverse_bind = inverse_bind; j->joint_box = joint_box; j->poses = poses; j->planes = planes;
-    j->parent = parent; j->palette = palette; j->world_aabb = world_aabb; j->culled = culled;
+    j->inverse_bind = inverse_bind; j->joint_box = joint_box; j->poses = poses;
+    j->parent = parent; j->palette = palette; j->local_box = local_box;
   }
   for (uint32_t t = 1; t < threads; ++t)
     if (pthread_create(&tids[t], NULL, skin_range, &jobs[t]) != 0) return -1;
@@ -731,26 +713,35 @@ int orc_skinned_bounds(uint32_t n, const float* pos_xyz, const float* rot_ijkw, 
   return 0;
 }
 
-/* The frame of skinned instances: model matrices as always, CoarseCulled and world_aabb from the
- * skinned bounds, then bitmap, emission and compaction unchanged. */
+/* The frame of skinned instances: the posed mesh-space box takes the place of GltfMesh.aabb, and the
+ * reference path runs on it unchanged (model matrix, aabb_calculation, coarse_culling, emission,
+ * compaction). */
 int orc_run_skinned(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, const uint32_t* mesh_id,
                     const OrcMesh* meshes, uint32_t m, uint32_t n_joints, const int32_t* parent, const float* inverse_bind,
                     const float* joint_box, const float* poses, const float planes[24], const float cam_pos[3],
                     uint32_t first_instance_base, uint32_t first_index_base, OrcOutputs* out, float* palette,
-                    uint32_t threads) {
+                    float* local_box_out, uint32_t threads) {
   if (check_mesh_ids(n, mesh_id, m)) return -1;
   uint8_t* culled = out->coarse_culled;
   uint8_t* culled_owned = NULL;
-  if (!culled) {
-    culled = culled_owned = (uint8_t*)malloc(n ? n : 1);
-    if (!culled) return -1;
-  }
-  if (out->model)
-    for (uint32_t i = 0; i < n; ++i)
-      orc_model_matrix(&pos_xyz[(size_t)i * 3], &rot_ijkw[(size_t)i * 4], scale[i], &out->model[(size_t)i * 16]);
-  int rc = orc_skinned_bounds(n, pos_xyz, rot_ijkw, scale, n_joints, parent, inverse_bind, joint_box, poses, planes,
-                              palette, out->world_aabb, culled, threads);
+  float* box = local_box_out;
+  float* box_owned = NULL;
+  if (!culled) culled = culled_owned = (uint8_t*)malloc(n ? n : 1);
+  if (!box) box = box_owned = (float*)malloc((size_t)(n ? n : 1) * 6 * sizeof(float));
+  int rc = (culled && box) ? 0 : -1;
+  if (rc == 0) rc = orc_skinned_bounds(n, n_joints, parent, inverse_bind, joint_box, poses, palette, box, threads);
   if (rc == 0) {
+    for (uint32_t i = 0; i < n; ++i) {
+      float m16[16], mins[3], maxs[3];
+      orc_model_matrix(&pos_xyz[(size_t)i * 3], &rot_ijkw[(size_t)i * 4], scale[i], m16);
+      orc_world_aabb(m16, &box[(size_t)i * 6], &box[(size_t)i * 6 + 3], mins, maxs);
+      culled[i] = (uint8_t)orc_coarse_culled(mins, maxs, planes);
+      if (out->model) memcpy(&out->model[(size_t)i * 16], m16, sizeof m16);
+      if (out->world_aabb) {
+        memcpy(&out->world_aabb[(size_t)i * 6], mins, sizeof mins);
+        memcpy(&out->world_aabb[(size_t)i * 6 + 3], maxs, sizeof maxs);
+      }
+    }
     if (out->visible_bitmap) pack_bitmap(n, culled, out->visible_bitmap);
     out->draw_count = 0;
     out->draw_index_total = 0;
@@ -766,5 +757,6 @@ int orc_run_skinned(uint32_t n, const float* pos_xyz, const float* rot_ijkw, con
     }
   }
   free(culled_owned);
+  free(box_owned);
   return rc;
 }

@@ -174,19 +174,20 @@ void orc_light_draw_lists(uint32_t n, const float* pos_xyz, const uint32_t* mesh
 /* ---- Extension: skinned instances (BASELINE config 5) — NOT a reference behaviour (the reference has
  * no skins). glTF 2.0 section 3.7.3: L_k = T*R*S of the pose (10 floats per joint:
  * t xyz, q ijkw, s xyz), G_k = G_parent*L_k (parent[k] < k or -1), J_k = G_k*inverse_bind_k, all as
- * affine 3x4 products in the order of orc_affine_mul; bounds = union over joints with a non-empty box
- * of the 8 corners of joint_box_k under (rows 0..2 of M)*J_k, then the rigid path's centre/half round
- * trip and plane test. palette: n x n_joints x 16 (mat4 column-major) or NULL. */
+ * affine 3x4 products in the order of orc_affine_mul. The posed box (mesh space) = fold, over the
+ * joints with a non-empty box in ascending order, of the 8 corners of joint_box_k under J_k (corner
+ * order and NaN-ignoring min/max of src/ecs.rs:146-173; seeds +-f32::MAX). It replaces GltfMesh.aabb
+ * for the instance and the reference path runs on it unchanged. palette: n x n_joints x 16 (mat4
+ * column-major) or NULL; local_box: n x 6 (min xyz, max xyz). */
 void orc_affine_mul(const float a[12], const float b[12], float out[12]);
 void orc_joint_local(const float trs[10], float l[12]);
-int orc_skinned_bounds(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, uint32_t n_joints,
-                       const int32_t* parent, const float* inverse_bind, const float* joint_box, const float* poses,
-                       const float planes[24], float* palette, float* world_aabb, uint8_t* culled, uint32_t threads);
+int orc_skinned_bounds(uint32_t n, uint32_t n_joints, const int32_t* parent, const float* inverse_bind,
+                       const float* joint_box, const float* poses, float* palette, float* local_box, uint32_t threads);
 int orc_run_skinned(uint32_t n, const float* pos_xyz, const float* rot_ijkw, const float* scale, const uint32_t* mesh_id,
                     const OrcMesh* meshes, uint32_t m, uint32_t n_joints, const int32_t* parent, const float* inverse_bind,
                     const float* joint_box, const float* poses, const float planes[24], const float cam_pos[3],
                     uint32_t first_instance_base, uint32_t first_index_base, OrcOutputs* out, float* palette,
-                    uint32_t threads);
+                    float* local_box_out, uint32_t threads);
 
 /* CameraMatrices.pv = projection * view for orc_project_camera's camera (column-major). */
 void orc_camera_pv(const float cam_pos[3], const float cam_rot_ijkw[4], float aspect, float fovy_degrees,

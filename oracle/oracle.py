@@ -279,10 +279,12 @@ def run_skinned(pos_xyz, rot_ijkw, scale, mesh_id, meshes, skeleton, poses, plan
     palette = None
     if "palette" in want:
         palette = res["palette"] = np.empty((n, n_joints, 16), np.float32)
+    local_box = res["local_box"] = np.empty((n, 6), np.float32)
     rc = lib().orc_run_skinned(C.c_uint32(n), _p(pos_xyz), _p(rot_ijkw), _p(scale), _p(mesh_id), _p(meshes),
                                C.c_uint32(len(meshes)), C.c_uint32(n_joints), _p(parent), _p(ibm), _p(box), _p(poses),
                                _p(planes), _p(cam_pos), C.c_uint32(first_instance_base), C.c_uint32(first_index_base),
-                               C.byref(o), _p(palette) if palette is not None else None, C.c_uint32(int(threads)))
+                               C.byref(o), _p(palette) if palette is not None else None, _p(local_box),
+                               C.c_uint32(int(threads)))
     if rc != 0:
         raise ValueError("oracle: bad skeleton, mesh id out of range or allocation failure")
     res["draw_count"] = int(o.draw_count)

@@ -79,7 +79,7 @@ struct KernelArgs {
   float* world_aabb;            // n*6 or null
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
-  const uint8_t* culled_override;  // n or null: CoarseCulled decided by an earlier kernel (skinned instances)
+  const float* box_override;    // n*6 or null: per-instance mesh-space box (min xyz, max xyz) that replaces the mesh table's (skinned instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
@@ -484,6 +484,14 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
     for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  if (a.box_override) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
+    const float2* b2 = reinterpret_cast<const float2*>(a.box_override + (size_t)il * 6);
+    const float2 b01 = b2[0], b23 = b2[1], b45 = b2[2];
+    mb.min_x = b01.x; mb.min_y = b01.y; mb.min_z = b23.x;
+    mb.max_x = b23.y; mb.max_y = b45.x; mb.max_z = b45.y;
+    // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
+    mag += fabsf(b01.x) + fabsf(b01.y) + fabsf(b23.x) + fabsf(b23.y) + fabsf(b45.x) + fabsf(b45.y);
+  }
   const bool all_finite = mag < 3.0e38f;
   Instance inst;
   if (__builtin_expect(__any(!all_finite), 0)) {
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
 
   MIP_STAMP(1);
   // ---- frustum test, LOD, command length ----
-  const bool culled = a.culled_override ? a.culled_override[il] != 0 : coarse_culled(inst, a.planes);
+  const bool culled = coarse_culled(inst, a.planes);
   const bool visible = active && !culled;
   const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
   const float dist_sq = dx * dx + dy * dy + dz * dz;
@@ -1017,26 +1025,26 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
 }
 
 // ---------------------------------------------------------------------------------------
-// Extension (BASELINE config 5): skinned instances — joint palette + bounds of the posed mesh
+// Extension (BASELINE config 5): skinned instances — joint palette + posed mesh-space box
 // ---------------------------------------------------------------------------------------
 // The reference has no skinning: this is specified from glTF 2.0
 // (section 3.7.3, skins) and checked against this repository's oracle only (orc_skinned_bounds).
 //   L_k = T(t_k) * R(q_k) * S(s_k)           the animated LOCAL transform of joint k
 //   G_k = G_parent(k) * L_k                  (roots: G_k = L_k; parents precede children)
 //   J_k = G_k * inverseBind_k                the palette entry the vertex shader blends
-//   box = union over k of (M * J_k) * joint_box_k      (M = the instance's model matrix)
+//   posed box = union over k of J_k * joint_box_k          (mesh space, 8 corners per joint)
 // A skinned vertex is a convex combination of J_k * v over the joints that influence it, so the
-// union of the transformed per-joint bind-pose boxes bounds the posed mesh. All matrices are
-// affine 3x4 (column-major, a[c*3 + r]); a product is, per column c, the column axpys
-// (a0*b0c + a1*b1c) + a2*b2c, plus "+ a3" for the translation column — no FMA, this order.
-// The box then goes through the same centre/half round trip and plane test as a rigid instance
-// (rows a-2, a-3), and the byte written here replaces coarse_culled() in the instance kernel
-// (KernelArgs.culled_override), which emits matrices, bitmap and commands as for any frame.
+// union of the transformed per-joint bind-pose boxes bounds the posed mesh. That box takes the
+// place of GltfMesh.aabb for the instance: the instance kernel reads it (KernelArgs.box_override)
+// and runs rows a-2 / a-3 / a-7 on it unchanged — 8 corners under M, fold, centre/half round
+// trip, planes, command. All matrices here are affine 3x4 (column-major, a[c*3 + r]); a product
+// is, per column c, the column axpys (a0*b0c + a1*b1c) + a2*b2c, plus "+ a3" for the
+// translation column — no FMA, this order.
 //
 // Mapping: one lane per (instance, joint). A wave holds floor(64 / J) instances; the parent's
 // matrix comes from the parent's lane (ds_bpermute), one round per hierarchy level. Poses are
 // read and palettes written through LDS so that every global access is lane-contiguous
-// (J*40 B in, J*64 B out per instance). HBM-bound: 40 B read + 64 B written per joint.
+// (J*40 B in, J*64 B out per instance). 40 B read + 64 B written per joint.
 constexpr uint32_t kMaxJoints = 32;
 constexpr uint32_t kPoseWords = 10;  // t xyz, q ijkw, s xyz
 
@@ -1049,18 +1057,13 @@ struct alignas(16) JointEntry {
 static_assert(sizeof(JointEntry) == 80, "JointEntry layout");
 
 struct SkinArgs {
-  const float* pos;            // n*3
-  const float4* rot;           // n
-  const float* scale;          // n
   const float* poses;          // n * J * 10
   const JointEntry* joints;    // J
   float4* palette;             // n * J * 4 (mat4 column-major) or null
-  float* world_aabb;           // n*6 or null
-  uint8_t* culled;             // n
+  float* local_box;            // n*6: min xyz, max xyz of the posed mesh (the fold's raw result)
   uint32_t n;
   uint32_t n_joints;
   uint32_t max_depth;
-  float planes[24];
 };
 
 __device__ __forceinline__ void affine_mul(const float (&a)[12], const float (&b)[12], float (&o)[12]) {
@@ -1093,27 +1096,12 @@ __global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs 
     const uint32_t words = in_wave * J * kPoseWords;
     for (uint32_t w = lane; w < words; w += 64u) io[w] = src[w];
   }
-  // instance columns (the J lanes of an instance read the same 36 B)
-  const float px = a.pos[3 * (size_t)inst + 0], py = a.pos[3 * (size_t)inst + 1], pz = a.pos[3 * (size_t)inst + 2];
-  const float4 q = a.rot[inst];
-  const float sc = a.scale[inst];
-  const JointEntry je = a.joints[valid ? joint : 0u];
-
-  // ---- model matrix exactly as the instance kernel builds it ----
-  float r[3][3];
-  quat_to_rotation(q.x, q.y, q.z, q.w, r);
-  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
-#pragma unroll
-  for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
-  Instance mi;
-  if (__builtin_expect(__any(!(mag < 3.0e38f)), 0)) {
-    float m16[16];
-    model_general(r, px, py, pz, sc, mi, m16);
-  } else {
-    model_fast(r, px, py, pz, sc, mi);
-  }
+  const float4* jp = reinterpret_cast<const float4*>(&a.joints[valid ? joint : 0u]);
+  const float4 j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
+  const float ibm[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
+  const float box[6] = {j3.x, j3.y, j3.z, j3.w, j4.x, j4.y};
+  const int parent = __float_as_int(j4.z);
+  const uint32_t depth = __float_as_uint(j4.w);
 
   // ---- local transform ----
   __builtin_amdgcn_wave_barrier();
@@ -1133,30 +1121,28 @@ __global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs 
   for (int k = 0; k < 12; ++k) L[k] = G[k];
 
   // ---- hierarchy: one round per level, parents sit in lower lanes of the same instance ----
-  const int parent_lane = (int)(lane - joint) + (je.parent < 0 ? (int)joint : je.parent);
+  const int parent_lane = (int)(lane - joint) + (parent < 0 ? (int)joint : parent);
   for (uint32_t d = 1; d <= a.max_depth; ++d) {
     float P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k)
       P[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(parent_lane << 2, __float_as_int(G[k])));
-    if (je.depth == d) affine_mul(P, L, G);
+    if (depth == d) affine_mul(P, L, G);
   }
 
-  // ---- palette entry and this joint's share of the bounds ----
+  // ---- palette entry and this joint's share of the posed box ----
   float Jm[12];
-  affine_mul(G, je.ibm, Jm);
-  float W[12];
-  affine_mul(mi.m, Jm, W);
+  affine_mul(G, ibm, Jm);
   float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
   float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
-  const bool has_box = valid && !(je.box[0] > je.box[3] || je.box[1] > je.box[4] || je.box[2] > je.box[5]);
+  const bool has_box = valid && !(box[0] > box[3] || box[1] > box[4] || box[2] > box[5]);
   if (has_box) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {  // corner order of src/ecs.rs:149-160
-      const float x = je.box[(c & 1) ? 3 : 0], z = je.box[(c & 2) ? 5 : 2], y = je.box[(c & 4) ? 4 : 1];
+      const float x = box[(c & 1) ? 3 : 0], z = box[(c & 2) ? 5 : 2], y = box[(c & 4) ? 4 : 1];
       float v[3];
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) v[rr] = W[0 * 3 + rr] * x + W[1 * 3 + rr] * y + W[2 * 3 + rr] * z + W[9 + rr];
+      for (int rr = 0; rr < 3; ++rr) v[rr] = Jm[0 * 3 + rr] * x + Jm[1 * 3 + rr] * y + Jm[2 * 3 + rr] * z + Jm[9 + rr];
       fold_corner(v, lo, hi);
     }
   }
@@ -1173,14 +1159,10 @@ __global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs 
     }
   }
   if (valid && joint == 0u) {
-    finish_aabb(lo, hi, mi);
-    a.culled[inst] = coarse_culled(mi, a.planes) ? 1 : 0;
-    if (a.world_aabb) {
-      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)inst * 6);
-      o2[0] = make_float2(mi.mins[0], mi.mins[1]);
-      o2[1] = make_float2(mi.mins[2], mi.maxs[0]);
-      o2[2] = make_float2(mi.maxs[1], mi.maxs[2]);
-    }
+    float2* o2 = reinterpret_cast<float2*>(a.local_box + (size_t)inst * 6);
+    o2[0] = make_float2(lo[0], lo[1]);
+    o2[1] = make_float2(lo[2], hi[0]);
+    o2[2] = make_float2(hi[1], hi[2]);
   }
 
   // ---- palette: mat4 per joint, staged so that each store instruction is 1 KiB contiguous ----

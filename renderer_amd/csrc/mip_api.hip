@@ -82,7 +82,7 @@ struct MipContext {
   float* d_poses_owned = nullptr;
   const float* d_poses = nullptr;  // owned copy or a borrowed device pointer
   uint32_t poses_n = 0;
-  uint8_t* d_skin_culled = nullptr;  // per instance CoarseCulled of the skinned box
+  float* d_skin_box = nullptr;  // per instance posed mesh-space box (min xyz, max xyz)
   int cu_count = 0;
   // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
@@ -292,7 +292,7 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_indices);
   (void)hipFree(ctx->d_joints);
   (void)hipFree(ctx->d_poses_owned);
-  (void)hipFree(ctx->d_skin_culled);
+  (void)hipFree(ctx->d_skin_box);
   for (auto& sl : ctx->slots) {
     (void)hipFree(sl.d_status);
     (void)hipFree(sl.d_scalars);
@@ -556,9 +556,8 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     a.src_index_offset = sl.d_tmp_src;
   }
   if (skinned) {
-    // the skinned box decides CoarseCulled (and is what world_aabb reports); launched first, same stream
-    a.culled_override = ctx->d_skin_culled;
-    a.world_aabb = nullptr;
+    // the posed mesh-space box replaces the mesh table's; computed first, on the same stream
+    a.box_override = ctx->d_skin_box;
   }
 
   // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh tag per launch marks
@@ -581,16 +580,13 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     if (skinned) {
       mip::SkinArgs k{};
-      k.pos = ctx->d_pos; k.rot = ctx->d_rot; k.scale = ctx->d_scale;
       k.poses = ctx->d_poses;
       k.joints = ctx->d_joints;
       k.palette = (float4*)palette;
-      k.world_aabb = (float*)out->world_aabb;
-      k.culled = ctx->d_skin_culled;
+      k.local_box = ctx->d_skin_box;
       k.n = n;
       k.n_joints = ctx->n_joints;
       k.max_depth = ctx->max_joint_depth;
-      std::memcpy(k.planes, frame->planes, sizeof k.planes);
       const uint32_t per_block = 4u * (64u / ctx->n_joints);
       hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(256), 0, stream, k);
       MIP_HIP(ctx, hipGetLastError());
@@ -869,7 +865,7 @@ int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs
   if (!ctx->n_joints || ctx->poses_n != ctx->n || (ctx->n && !ctx->d_poses))
     return fail(ctx, MIP_ERR_NOT_READY, "skeleton or poses not set for the resident instances");
   if (int32_t rc = bind_device(ctx)) return rc;
-  if (!ctx->d_skin_culled) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_culled, ctx->max_instances ? ctx->max_instances : 1));
+  if (!ctx->d_skin_box) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_box, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * 24));
   return run_frame(ctx, frame, out, true, palette);
 }
 

@@ -106,6 +106,22 @@ def test_other_joint_counts_and_hierarchies(ra, oracle_mod, j):
     _check(got, want, f"j={j}")
 
 
+def test_identity_skin_reproduces_the_rigid_path(ra, oracle_mod):
+    """One joint, identity pose and bind matrix, joint box = the mesh box: the skinned frame must be the
+    rigid frame of rows a-1..a-7, bit for bit (oracle.run, not run_skinned, is the expectation)."""
+    s = ra.scene.make_scene(2, n=20_000)
+    m = s["meshes"][0]
+    sk = dict(parent=np.array([-1], np.int32), inverse_bind=np.eye(4, dtype=np.float32).reshape(1, 16),
+              joint_box=np.concatenate([m["aabb_min"], m["aabb_max"]]).reshape(1, 6))
+    poses = np.zeros((s["n"], 1, 10), np.float32)
+    poses[:, :, 6] = 1.0
+    poses[:, :, 7:] = 1.0
+    want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"])
+    got = _run_gpu(ra, s, sk, poses)
+    want["palette"] = np.tile(np.eye(4, dtype=np.float32).reshape(16), (s["n"], 1, 1))
+    _check(got, want, "identity skin")
+
+
 def test_non_finite_and_degenerate_inputs(ra, oracle_mod):
     s = ra.scene.make_skinned_scene(600)
     poses = s["poses"].copy()

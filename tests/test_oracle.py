@@ -250,14 +250,32 @@ def test_skinned_extension_against_float64(oracle_mod):
             assert np.allclose(got["palette"][inst, k].reshape(4, 4).T, jm, rtol=1e-5, atol=1e-5)
             b = sk["joint_box"][k].astype(np.float64)
             for c in range(8):
-                v = model @ jm @ np.array([b[3 if c & 1 else 0], b[4 if c & 4 else 1], b[5 if c & 2 else 2], 1.0])
+                v = jm @ np.array([b[3 if c & 1 else 0], b[4 if c & 4 else 1], b[5 if c & 2 else 2], 1.0])
                 lo, hi = np.minimum(lo, v[:3]), np.maximum(hi, v[:3])
-        assert np.allclose(got["world_aabb"][inst], np.concatenate([lo, hi]), rtol=1e-4, atol=1e-4)
+        assert np.allclose(got["local_box"][inst], np.concatenate([lo, hi]), rtol=1e-5, atol=1e-5)
+        # the posed box then goes through aabb_calculation like any mesh box
+        wl, wh = np.full(3, np.inf), np.full(3, -np.inf)
+        for c in range(8):
+            v = model @ np.array([hi[0] if c & 1 else lo[0], hi[1] if c & 4 else lo[1], hi[2] if c & 2 else lo[2], 1.0])
+            wl, wh = np.minimum(wl, v[:3]), np.maximum(wh, v[:3])
+        assert np.allclose(got["world_aabb"][inst], np.concatenate([wl, wh]), rtol=1e-4, atol=1e-4)
     bind = poses[:4].copy()
     bind[:, :, 3:6], bind[:, :, 6], bind[:, :, 7:] = 0.0, 1.0, 1.0
     r0 = oracle_mod.run_skinned(s["pos"][:4], s["rot"][:4], s["scale"][:4], s["mesh_id"][:4], s["meshes"], sk, bind,
                                 s["planes"], s["cam_pos"])
     assert np.abs(r0["palette"] - np.eye(4, dtype=np.float32).reshape(16)).max() < 1e-6  # bind pose: identity palette
+    # one identity joint whose box is the mesh box: the skinned frame IS the rigid frame
+    rigid = scene.make_scene(2, n=3000)
+    m = rigid["meshes"][0]
+    one = dict(parent=np.array([-1], np.int32), inverse_bind=np.eye(4, dtype=np.float32).reshape(1, 16),
+               joint_box=np.concatenate([m["aabb_min"], m["aabb_max"]]).reshape(1, 6))
+    ident = np.zeros((3000, 1, 10), np.float32)
+    ident[:, :, 6], ident[:, :, 7:] = 1.0, 1.0
+    a = oracle_mod.run_skinned(rigid["pos"], rigid["rot"], rigid["scale"], rigid["mesh_id"], rigid["meshes"], one, ident,
+                               rigid["planes"], rigid["cam_pos"])
+    b = oracle_mod.run(rigid["pos"], rigid["rot"], rigid["scale"], rigid["mesh_id"], rigid["meshes"], rigid["planes"], rigid["cam_pos"])
+    assert a["draw_cmds"].tobytes() == b["draw_cmds"].tobytes() and np.array_equal(a["world_aabb"], b["world_aabb"])
+    assert np.array_equal(a["visible_bitmap"], b["visible_bitmap"])
     with pytest.raises(ValueError):
         oracle_mod.run_skinned(s["pos"][:4], s["rot"][:4], s["scale"][:4], s["mesh_id"][:4], s["meshes"],
                                dict(sk, parent=np.array([0] + list(sk["parent"][1:]), np.int32)), bind, s["planes"], s["cam_pos"])
