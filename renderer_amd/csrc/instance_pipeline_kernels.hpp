@@ -1041,29 +1041,41 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
 // is, per column c, the column axpys (a0*b0c + a1*b1c) + a2*b2c, plus "+ a3" for the
 // translation column — no FMA, this order.
 //
-// Mapping: one lane per (instance, joint). A wave holds floor(64 / J) instances; the parent's
-// matrix comes from the parent's lane (ds_bpermute), one round per hierarchy level. Poses are
-// read and palettes written through LDS so that every global access is lane-contiguous
-// (J*40 B in, J*64 B out per instance). 40 B read + 64 B written per joint.
+// Mapping: one lane per (instance, joint); a wave holds floor(64 / J) instances, a workgroup four
+// waves. The two steps that would run mostly idle lanes are re-packed through LDS:
+//   hierarchy  level by level over the whole workgroup: the (instance, joint) pairs of one depth
+//              are dense in the thread index, so a level costs one or two wave-wide 3x4 products
+//              per workgroup instead of one per wave and level (a lane-per-joint loop leaves
+//              4 of 5 lanes idle on a humanoid);
+//   box fold   one thread per (instance, component) runs over the joints in ascending order —
+//              the oracle's order — instead of a log-step exchange of six values per lane.
+// Poses are read as five 8-byte loads per lane (40 B, lane-contiguous) and palette entries
+// written as four 16-byte stores per lane (64 B, lane-contiguous): 40 B read + 64 B written per
+// joint. What bounds the kernel is workgroup lifetime x resident workgroups (its phases are
+// separated by barriers), so registers and LDS are kept small: 66 VGPRs, 18 KB, 7 waves per SIMD.
 constexpr uint32_t kMaxJoints = 32;
 constexpr uint32_t kPoseWords = 10;  // t xyz, q ijkw, s xyz
+constexpr uint32_t kSkinBlock = 256;
 
 struct alignas(16) JointEntry {
   float ibm[12];     // rows 0..2 of inverseBindMatrices[k], column-major 3x4
   float box[6];      // min xyz, max xyz of the bind-pose vertices weighted to this joint; min > max: none
   int32_t parent;    // < k, or -1
-  uint32_t depth;    // 0 for roots
+  uint32_t sorted;   // entry i: the i-th joint in depth order and its parent, joint | parent << 8
 };
 static_assert(sizeof(JointEntry) == 80, "JointEntry layout");
 
 struct SkinArgs {
-  const float* poses;          // n * J * 10
+  const float* poses;          // n * J * 10, 8-byte aligned
   const JointEntry* joints;    // J
   float4* palette;             // n * J * 4 (mat4 column-major) or null
   float* local_box;            // n*6: min xyz, max xyz of the posed mesh (the fold's raw result)
   uint32_t n;
   uint32_t n_joints;
   uint32_t max_depth;
+  uint32_t inv_joints;                      // ceil(2^16 / J): x / J == (x * inv) >> 16 for x < 256
+  uint32_t level_inv[kMaxJoints + 1];       // ceil(2^16 / joints at depth d)
+  uint8_t level_start[kMaxJoints + 2];      // depth d owns sorted entries [level_start[d], level_start[d+1])
 };
 
 __device__ __forceinline__ void affine_mul(const float (&a)[12], const float (&b)[12], float (&o)[12]) {
@@ -1077,37 +1089,49 @@ __device__ __forceinline__ void affine_mul(const float (&a)[12], const float (&b
     }
 }
 
-__global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_io[4][64 * 16];  // per wave: poses in (<= 640 words), palette out (<= 1024)
+__device__ __forceinline__ void lds_read12(const float* p, float (&m)[12]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  const float4 a = q[0], b = q[1], c = q[2];
+  m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+  m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w;
+}
+
+__device__ __forceinline__ void lds_write12(float* p, const float (&m)[12]) {
+  float4* q = reinterpret_cast<float4*>(p);
+  q[0] = make_float4(m[0], m[1], m[2], m[3]);
+  q[1] = make_float4(m[4], m[5], m[6], m[7]);
+  q[2] = make_float4(m[8], m[9], m[10], m[11]);
+}
+
+__global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const SkinArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_g[kSkinBlock * 12];   // L, then G, per (instance, joint) pair
+  __shared__ float s_box[kSkinBlock * 6];                                // per pair: lo xyz, hi xyz
+  __shared__ uint32_t s_sorted[kMaxJoints];                              // joints in depth order (joint | parent << 8)
+  __shared__ uint32_t s_level[kMaxJoints + 2];                           // per depth: first sorted entry | ceil(2^16/count) << 8
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t J = a.n_joints;
-  const uint32_t ipw = 64u / J;                       // instances per wave
-  const uint32_t wave_first = (blockIdx.x * 4u + wave) * ipw;
-  if (wave_first >= a.n) return;                      // whole wave idle (no block-level barriers below)
-  const uint32_t in_wave = a.n - wave_first < ipw ? a.n - wave_first : ipw;
-  const uint32_t g = lane / J, joint = lane - g * J;
-  const bool valid = g < in_wave;
-  const uint32_t inst = wave_first + (valid ? g : 0u);
-  float* io = s_io[wave];
+  // The hierarchy loop below is a chain of short dependent steps; its per-level look-ups come from
+  // LDS (a global or kernarg load per level would put ~1 us of cache latency on that chain).
+  if (tid < J) s_sorted[tid] = a.joints[tid].sorted;
+  if (tid < kMaxJoints + 2u) s_level[tid] = (uint32_t)a.level_start[tid] | ((tid <= kMaxJoints ? a.level_inv[tid] : 0u) << 8);
+  const uint32_t ipw = 64u / J, ipb = 4u * ipw;           // instances per wave / workgroup
+  const uint32_t block_first = blockIdx.x * ipb;          // < n by the grid size
+  const uint32_t in_block = a.n - block_first < ipb ? a.n - block_first : ipb;
+  const uint32_t g = (lane * a.inv_joints) >> 16, joint = lane - g * J;
+  const uint32_t li = wave * ipw + g;                     // instance within the workgroup
+  const bool valid = g < ipw && li < in_block;
+  const uint32_t pair = valid ? li * J + joint : 0u;      // == wave*ipw*J + lane for valid lanes
 
-  // ---- poses: the wave's in_wave*J*10 words are contiguous ----
-  {
-    const float* src = a.poses + (size_t)wave_first * J * kPoseWords;
-    const uint32_t words = in_wave * J * kPoseWords;
-    for (uint32_t w = lane; w < words; w += 64u) io[w] = src[w];
-  }
+  // ---- pose and joint constants ----
+  const float2* pp = reinterpret_cast<const float2*>(a.poses + ((size_t)block_first * J + pair) * kPoseWords);
+  const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4];
+  const float t[kPoseWords] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y, p4.x, p4.y};
   const float4* jp = reinterpret_cast<const float4*>(&a.joints[valid ? joint : 0u]);
   const float4 j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
   const float ibm[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
   const float box[6] = {j3.x, j3.y, j3.z, j3.w, j4.x, j4.y};
-  const int parent = __float_as_int(j4.z);
-  const uint32_t depth = __float_as_uint(j4.w);
 
-  // ---- local transform ----
-  __builtin_amdgcn_wave_barrier();
-  float t[kPoseWords];
-#pragma unroll
-  for (uint32_t k = 0; k < kPoseWords; ++k) t[k] = io[(valid ? lane : 0u) * kPoseWords + k];
+  // ---- local transform L = T * R * S ----
   float lr[3][3];
   quat_to_rotation(t[3], t[4], t[5], t[6], lr);
   float G[12];
@@ -1116,27 +1140,42 @@ __global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs 
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) G[c * 3 + rr] = lr[rr][c] * t[7 + c];
   G[9] = t[0]; G[10] = t[1]; G[11] = t[2];
-  float L[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) L[k] = G[k];
+  if (valid) lds_write12(&s_g[pair * 12u], G);
+  __syncthreads();
 
-  // ---- hierarchy: one round per level, parents sit in lower lanes of the same instance ----
-  const int parent_lane = (int)(lane - joint) + (parent < 0 ? (int)joint : parent);
+  // ---- hierarchy, one level at a time over the whole workgroup ----
   for (uint32_t d = 1; d <= a.max_depth; ++d) {
-    float P[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k)
-      P[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(parent_lane << 2, __float_as_int(G[k])));
-    if (depth == d) affine_mul(P, L, G);
+    const uint32_t lv = s_level[d];
+    const uint32_t start = lv & 0xffu, cnt = (s_level[d + 1] & 0xffu) - start, inv = lv >> 8;
+    if (tid < in_block * cnt) {
+      const uint32_t inst_l = (tid * inv) >> 16;  // tid / cnt
+      const uint32_t packed = s_sorted[start + (tid - inst_l * cnt)];
+      const uint32_t k = packed & 0xffu, pk = packed >> 8;
+      float P[12], Lk[12], Gk[12];
+      lds_read12(&s_g[(inst_l * J + pk) * 12u], P);
+      lds_read12(&s_g[(inst_l * J + k) * 12u], Lk);
+      affine_mul(P, Lk, Gk);
+      lds_write12(&s_g[(inst_l * J + k) * 12u], Gk);
+    }
+    __syncthreads();
   }
+  if (a.max_depth) lds_read12(&s_g[pair * 12u], G);
 
-  // ---- palette entry and this joint's share of the posed box ----
+  // ---- palette entry (mat4 per joint: 64 B per lane, lane-contiguous) ----
   float Jm[12];
   affine_mul(G, ibm, Jm);
+  if (a.palette && valid) {
+    float4* out = a.palette + ((size_t)block_first * J + pair) * 4u;
+    out[0] = make_float4(Jm[0], Jm[1], Jm[2], 0.0f);
+    out[1] = make_float4(Jm[3], Jm[4], Jm[5], 0.0f);
+    out[2] = make_float4(Jm[6], Jm[7], Jm[8], 0.0f);
+    out[3] = make_float4(Jm[9], Jm[10], Jm[11], 1.0f);
+  }
+
+  // ---- this joint's share of the posed box ----
   float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
   float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
-  const bool has_box = valid && !(box[0] > box[3] || box[1] > box[4] || box[2] > box[5]);
-  if (has_box) {
+  if (!(box[0] > box[3] || box[1] > box[4] || box[2] > box[5])) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {  // corner order of src/ecs.rs:149-160
       const float x = box[(c & 1) ? 3 : 0], z = box[(c & 2) ? 5 : 2], y = box[(c & 4) ? 4 : 1];
@@ -1146,37 +1185,31 @@ __global__ __launch_bounds__(256) void mip_skinned_bounds_kernel(const SkinArgs 
       fold_corner(v, lo, hi);
     }
   }
-  // fold over the instance's joints: min/max ignore NaN and are order-independent otherwise
-  for (uint32_t step = 1; step < J; step <<= 1) {
-    const bool take = joint + step < J;
-    const int from = (int)(take ? lane + step : lane) << 2;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float ol = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(lo[k])));
-      const float oh = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(hi[k])));
-      lo[k] = fminf(lo[k], ol);
-      hi[k] = fmaxf(hi[k], oh);
-    }
+  if (valid) {
+    float2* b2 = reinterpret_cast<float2*>(&s_box[pair * 6u]);
+    b2[0] = make_float2(lo[0], lo[1]);
+    b2[1] = make_float2(lo[2], hi[0]);
+    b2[2] = make_float2(hi[1], hi[2]);
   }
-  if (valid && joint == 0u) {
-    float2* o2 = reinterpret_cast<float2*>(a.local_box + (size_t)inst * 6);
-    o2[0] = make_float2(lo[0], lo[1]);
-    o2[1] = make_float2(lo[2], hi[0]);
-    o2[2] = make_float2(hi[1], hi[2]);
-  }
+  __syncthreads();
 
-  // ---- palette: mat4 per joint, staged so that each store instruction is 1 KiB contiguous ----
-  if (a.palette) {
-    __builtin_amdgcn_wave_barrier();  // every lane has read its pose words
-    float4* st = reinterpret_cast<float4*>(io) + lane * 4u;
-    st[0] = make_float4(Jm[0], Jm[1], Jm[2], 0.0f);
-    st[1] = make_float4(Jm[3], Jm[4], Jm[5], 0.0f);
-    st[2] = make_float4(Jm[6], Jm[7], Jm[8], 0.0f);
-    st[3] = make_float4(Jm[9], Jm[10], Jm[11], 1.0f);
-    __builtin_amdgcn_wave_barrier();
-    float4* out = a.palette + (size_t)wave_first * J * 4u;
-    const uint32_t quads = in_wave * J * 4u;
-    for (uint32_t w = lane; w < quads; w += 64u) out[w] = reinterpret_cast<const float4*>(io)[w];
+  // ---- fold over the joints, in the oracle's order: one thread per (instance, component) ----
+  for (uint32_t e = tid; e < in_block * 6u; e += kSkinBlock) {
+    const uint32_t inst_l = e / 6u, comp = e - inst_l * 6u;
+    const bool is_min = comp < 3u;
+    float v = is_min ? 3.40282347e+38f : -3.40282347e+38f;
+    const float* src = &s_box[inst_l * J * 6u + comp];
+    uint32_t k = 0;
+    for (; k + 4u <= J; k += 4u) {  // four reads in flight, folded in ascending order
+      const float x0 = src[k * 6u], x1 = src[k * 6u + 6u], x2 = src[k * 6u + 12u], x3 = src[k * 6u + 18u];
+      // f32::min / f32::max: a NaN operand is ignored
+      v = is_min ? fminf(fminf(fminf(fminf(v, x0), x1), x2), x3) : fmaxf(fmaxf(fmaxf(fmaxf(v, x0), x1), x2), x3);
+    }
+    for (; k < J; ++k) {
+      const float x = src[k * 6u];
+      v = is_min ? fminf(v, x) : fmaxf(v, x);
+    }
+    a.local_box[(size_t)block_first * 6u + e] = v;
   }
 }
 

@@ -79,6 +79,8 @@ struct MipContext {
   // skinned extension (mip_set_skeleton / mip_set_poses / mip_run_skinned)
   mip::JointEntry* d_joints = nullptr;
   uint32_t n_joints = 0, max_joint_depth = 0;
+  uint8_t joint_level_start[mip::kMaxJoints + 2] = {0};
+  uint32_t joint_level_inv[mip::kMaxJoints + 1] = {0};
   float* d_poses_owned = nullptr;
   const float* d_poses = nullptr;  // owned copy or a borrowed device pointer
   uint32_t poses_n = 0;
@@ -587,8 +589,11 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       k.n = n;
       k.n_joints = ctx->n_joints;
       k.max_depth = ctx->max_joint_depth;
+      k.inv_joints = (65536u + ctx->n_joints - 1u) / ctx->n_joints;
+      std::memcpy(k.level_start, ctx->joint_level_start, sizeof k.level_start);
+      std::memcpy(k.level_inv, ctx->joint_level_inv, sizeof k.level_inv);
       const uint32_t per_block = 4u * (64u / ctx->n_joints);
-      hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(256), 0, stream, k);
+      hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(mip::kSkinBlock), 0, stream, k);
       MIP_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, stream, a);
@@ -812,6 +817,7 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
   if (n_joints == 0 || n_joints > MIP_MAX_JOINTS)
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_joints %u outside 1..%u", n_joints, (unsigned)MIP_MAX_JOINTS);
   std::vector<mip::JointEntry> joints(n_joints);
+  std::vector<uint32_t> depth(n_joints);
   uint32_t max_depth = 0;
   for (uint32_t k = 0; k < n_joints; ++k) {
     if (parent[k] >= (int32_t)k || parent[k] < -1)
@@ -821,9 +827,21 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
       for (int r = 0; r < 3; ++r) j.ibm[c * 3 + r] = inverse_bind[(size_t)k * 16 + c * 4 + r];
     std::memcpy(j.box, joint_box + (size_t)k * 6, sizeof j.box);
     j.parent = parent[k];
-    j.depth = parent[k] < 0 ? 0u : joints[parent[k]].depth + 1u;
-    if (j.depth > max_depth) max_depth = j.depth;
+    depth[k] = parent[k] < 0 ? 0u : depth[parent[k]] + 1u;
+    if (depth[k] > max_depth) max_depth = depth[k];
   }
+  // joints in depth order (stable): level d owns sorted entries [level_start[d], level_start[d+1])
+  uint8_t level_start[mip::kMaxJoints + 2] = {0};
+  uint32_t level_inv[mip::kMaxJoints + 1] = {0};
+  uint32_t at = 0;
+  for (uint32_t d = 0; d <= max_depth; ++d) {
+    level_start[d] = (uint8_t)at;
+    for (uint32_t k = 0; k < n_joints; ++k)
+      if (depth[k] == d) joints[at++].sorted = k | ((uint32_t)(parent[k] < 0 ? 0 : parent[k]) << 8);
+    const uint32_t cnt = at - level_start[d];
+    level_inv[d] = (65536u + cnt - 1u) / cnt;
+  }
+  for (uint32_t d = max_depth + 1; d < mip::kMaxJoints + 2; ++d) level_start[d] = (uint8_t)at;
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (!ctx->d_joints) MIP_HIP(ctx, hipMalloc(&ctx->d_joints, sizeof(mip::JointEntry) * MIP_MAX_JOINTS));
@@ -834,6 +852,8 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
   }
   ctx->n_joints = n_joints;
   ctx->max_joint_depth = max_depth;
+  std::memcpy(ctx->joint_level_start, level_start, sizeof level_start);
+  std::memcpy(ctx->joint_level_inv, level_inv, sizeof level_inv);
   return MIP_OK;
 }
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Runs the skinned frame (BASELINE config 5 extension) K times; prints wall-clock per frame.
+usage: tools/skin_bench.py [n] [frames]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import renderer_amd
+from renderer_amd import scene
+from renderer_amd.pipeline import make_frame
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256_000
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+dev = torch.device("cuda", 0)
+s = scene.make_skinned_scene(n)
+sk = s["skeleton"]
+j = len(sk["parent"])
+p = renderer_amd.InstancePipeline(n, 1)
+p.set_mesh_table(s["meshes"])
+p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+p.set_skeleton(sk["parent"], sk["inverse_bind"], sk["joint_box"])
+poses = torch.from_numpy(s["poses"]).to(dev)
+torch.cuda.synchronize()
+p.set_poses_device(poses.data_ptr(), n)
+model = torch.empty((n, 16), dtype=torch.float32, device=dev)
+palette = torch.empty((n, j, 16), dtype=torch.float32, device=dev)
+bitmap = torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=dev)
+cmds = torch.empty((n, 5), dtype=torch.int32, device=dev)
+scal = torch.zeros(8, dtype=torch.int32, device=dev)
+frame = make_frame(s["planes"], s["cam_pos"])
+kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+          draw_index_total=scal.data_ptr() + 4)
+for variant, pal in (("with palette", palette.data_ptr()), ("bounds only", 0)):
+    for _ in range(5):
+        p.run_skinned(frame, palette=pal, async_=True, **kw)
+    p.wait()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        p.run_skinned(frame, palette=pal, async_=True, **kw)
+    p.wait()
+    dt = (time.perf_counter() - t0) / frames
+    print(f"n={n} J={j} {variant}: {dt*1e6:.1f} us/frame, {n/dt/1e9:.2f} G instances/s, commands {int(scal[0].item())}", flush=True)
+p.close()
