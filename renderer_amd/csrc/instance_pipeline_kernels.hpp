@@ -756,16 +756,24 @@ __device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x
   for (int r = 0; r < 4; ++r) o[r] = m[0 * 4 + r] * x + m[1 * 4 + r] * y + m[2 * 4 + r] * z + m[3 * 4 + r] * w;
 }
 
-// One triangle of generate_work.comp:132-155: true = culled (back-facing or beyond one x/y bound).
-__device__ __forceinline__ bool triangle_culled(const float (&model)[16], const float (&pv)[16], const float* vertices,
-                                                long long vertex_offset, uint32_t i0, uint32_t i1, uint32_t i2) {
+// The three positions of a triangle (packed vec3 each).
+__device__ __forceinline__ void triangle_fetch(const float* vertices, long long vertex_offset, uint32_t i0, uint32_t i1,
+                                               uint32_t i2, float (&v)[9]) {
   const uint32_t ix[3] = {i0, i1, i2};
-  float clip[3][4];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float* p = vertices + (vertex_offset + (long long)ix[k]) * 3;
+    v[k * 3 + 0] = p[0]; v[k * 3 + 1] = p[1]; v[k * 3 + 2] = p[2];
+  }
+}
+
+// One triangle of generate_work.comp:132-155: true = culled (back-facing or beyond one x/y bound).
+__device__ __forceinline__ bool triangle_test(const float (&model)[16], const float (&pv)[16], const float (&v)[9]) {
+  float clip[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
     float world[4];
-    glsl_mat4_mul_vec4(model, p[0], p[1], p[2], 1.0f, world);
+    glsl_mat4_mul_vec4(model, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], 1.0f, world);
     glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
   }
   const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
@@ -773,12 +781,34 @@ __device__ __forceinline__ bool triangle_culled(const float (&model)[16], const 
   const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][3];
   const float det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) + a20 * (a01 * a12 - a11 * a02);
   bool cull = det > 0.0f;
-  const float x0 = clip[0][0] / clip[0][3], y0 = clip[0][1] / clip[0][3];
-  const float x1 = clip[1][0] / clip[1][3], y1 = clip[1][1] / clip[1][3];
-  const float x2 = clip[2][0] / clip[2][3], y2 = clip[2][1] / clip[2][3];
-  cull = cull || (x0 < -1.0f && x1 < -1.0f && x2 < -1.0f) || (x0 > 1.0f && x1 > 1.0f && x2 > 1.0f) ||
-         (y0 < -1.0f && y1 < -1.0f && y2 < -1.0f) || (y0 > 1.0f && y1 > 1.0f && y2 > 1.0f);
-  return cull;
+  // ndc = clip.xy / clip.w compared with -1 and 1 (generate_work.comp:143-155), without dividing:
+  // for floats x, w the correctly rounded quotient q = RN(x / w) satisfies
+  //     q > 1  <=>  x*sgn(w) > |w|        q < -1  <=>  x*sgn(w) < -|w|
+  // because x*sgn(w) > |w| puts x/w at least one ulp(w)/|w| >= 2^-23 above 1, past the rounding
+  // boundary 1 + 2^-24, and x*sgn(w) <= |w| gives x/w <= 1. It also holds at w = +-0 (q = +-inf by
+  // the signs, NaN for 0/0), for infinities and NaNs (every comparison false), and for subnormals
+  // (tests/test_oracle.py::test_ndc_comparison_without_division checks it against real divisions).
+  // The six correctly rounded divides were 60 of the 197 VALU instructions of a step.
+  bool xl = true, xg = true, yl = true, yg = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t sw = __float_as_uint(clip[k][3]) & 0x80000000u;
+    const float w = fabsf(clip[k][3]);
+    const float x = __uint_as_float(__float_as_uint(clip[k][0]) ^ sw);
+    const float y = __uint_as_float(__float_as_uint(clip[k][1]) ^ sw);
+    xl = xl && (x < -w);
+    xg = xg && (x > w);
+    yl = yl && (y < -w);
+    yg = yg && (y > w);
+  }
+  return cull || xl || xg || yl || yg;
+}
+
+__device__ __forceinline__ bool triangle_culled(const float (&model)[16], const float (&pv)[16], const float* vertices,
+                                                long long vertex_offset, uint32_t i0, uint32_t i1, uint32_t i2) {
+  float v[9];
+  triangle_fetch(vertices, vertex_offset, i0, i1, i2, v);
+  return triangle_test(model, pv, v);
 }
 
 #ifndef MIP_TRI_MIN_WAVES_PER_SIMD

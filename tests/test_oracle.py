@@ -126,6 +126,46 @@ def test_lod_squared_distance_threshold_equivalence():
             assert bool(np.sqrt(special) > np.float32(10.0)) == bool(special > thr)
 
 
+def test_ndc_comparison_without_division():
+    """The triangle kernel tests RN(x/w) > 1 as x*sgn(w) > |w| (and < -1 as x*sgn(w) < -|w|) instead of
+    dividing. Check the equivalence against float32 divisions on the cases where it could break: x within a
+    few ulps of +-w over every exponent, subnormals, zeros of both signs, infinities, NaNs, random pairs."""
+    rng = np.random.default_rng(7)
+    ws = []
+    for e in list(range(-149, 128, 3)) + [-126, -127, -125, 127]:
+        base = np.float32(2.0) ** np.float32(e) if e > -127 else np.float32(np.ldexp(1.0, e))
+        for frac in (1.0, 1.0000001, 1.25, 1.5, 1.9999999):
+            ws.append(np.float32(base * np.float32(frac)))
+    ws = np.array(ws + [0.0, np.inf, np.nan, 1e-45, 3e-45, 1.1754942e-38, 1.1754944e-38, 3.4028235e38], np.float32)
+    ws = np.concatenate([ws, -ws])
+    xs_all, ws_all = [], []
+    np.seterr(all="ignore")
+    for w in ws:
+        near = np.full(17, abs(w), np.float32)
+        for k in range(8):
+            near[1 + k:] = np.nextafter(near[1 + k:], np.float32(np.inf))
+        down = np.full(9, abs(w), np.float32)
+        for k in range(8):
+            down[1 + k:] = np.nextafter(down[1 + k:], np.float32(0))
+        cand = np.concatenate([near[:9], down, [0.0, np.inf, np.nan, abs(w) * np.float32(2), abs(w) * np.float32(0.5)]]).astype(np.float32)
+        cand = np.concatenate([cand, -cand])
+        xs_all.append(cand)
+        ws_all.append(np.full(len(cand), w, np.float32))
+    xs = np.concatenate(xs_all + [rng.standard_normal(200_000).astype(np.float32) * np.float32(3),
+                                   (rng.integers(0, 2**32, 200_000, dtype=np.uint64).astype(np.uint32)).view(np.float32)])
+    wv = np.concatenate(ws_all + [rng.standard_normal(200_000).astype(np.float32),
+                                   (rng.integers(0, 2**32, 200_000, dtype=np.uint64).astype(np.uint32)).view(np.float32)])
+    with np.errstate(all="ignore"):
+        q = xs / wv                                              # IEEE binary32 division, round to nearest even
+        sign = wv.view(np.uint32) & np.uint32(0x80000000)
+        xf = (xs.view(np.uint32) ^ sign).view(np.float32)
+        wa = np.abs(wv)
+        assert np.array_equal(q > np.float32(1), xf > wa)
+        assert np.array_equal(q < np.float32(-1), xf < -wa)
+    np.seterr(all="warn")
+    assert len(xs) > 400_000
+
+
 def test_emit_and_compact_semantics(oracle_mod):
     from renderer_amd import scene
 
