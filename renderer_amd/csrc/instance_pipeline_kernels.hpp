@@ -25,6 +25,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #pragma clang fp contract(off)
@@ -746,6 +748,7 @@ struct TriangleArgs {
   uint32_t first_instance_base;
   uint32_t* error_flag;
   uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
+  uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
   float pv[16];
 };
 
@@ -768,13 +771,27 @@ __device__ __forceinline__ void triangle_fetch(const float* vertices, long long 
 }
 
 // One triangle of generate_work.comp:132-155: true = culled (back-facing or beyond one x/y bound).
+// kAffine: the caller has checked that row 3 of `model` is (0,0,0,1) and that the geometry holds
+// only finite positions. Then world.w = ((0*x + 0*y) + 0*z) + 1 is exactly 1 and pv[:,3] * world.w
+// is exactly pv[:,3], so that row and those four products are skipped: same bits, 126 instead
+// of 156 flops per triangle.
+template <bool kAffine>
 __device__ __forceinline__ bool triangle_test(const float (&model)[16], const float (&pv)[16], const float (&v)[9]) {
   float clip[3][4];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float world[4];
-    glsl_mat4_mul_vec4(model, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], 1.0f, world);
-    glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
+    if constexpr (kAffine) {
+      const float x = v[k * 3 + 0], y = v[k * 3 + 1], z = v[k * 3 + 2];
+      float world[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) world[r] = model[0 * 4 + r] * x + model[1 * 4 + r] * y + model[2 * 4 + r] * z + model[3 * 4 + r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) clip[k][r] = pv[0 * 4 + r] * world[0] + pv[1 * 4 + r] * world[1] + pv[2 * 4 + r] * world[2] + pv[3 * 4 + r];
+    } else {
+      float world[4];
+      glsl_mat4_mul_vec4(model, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], 1.0f, world);
+      glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
+    }
   }
   const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
   const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][3];
@@ -804,11 +821,16 @@ __device__ __forceinline__ bool triangle_test(const float (&model)[16], const fl
   return cull || xl || xg || yl || yg;
 }
 
-__device__ __forceinline__ bool triangle_culled(const float (&model)[16], const float (&pv)[16], const float* vertices,
+__device__ __forceinline__ bool triangle_culled(bool affine, const float (&model)[16], const float (&pv)[16], const float* vertices,
                                                 long long vertex_offset, uint32_t i0, uint32_t i1, uint32_t i2) {
   float v[9];
   triangle_fetch(vertices, vertex_offset, i0, i1, i2, v);
-  return triangle_test(model, pv, v);
+  return affine ? triangle_test<true>(model, pv, v) : triangle_test<false>(model, pv, v);  // wave-uniform
+}
+
+// Wave-uniform: may this command's triangles take the affine path?
+__device__ __forceinline__ bool model_is_affine(const float (&model)[16], uint32_t geometry_finite) {
+  return geometry_finite != 0u && model[3] == 0.0f && model[7] == 0.0f && model[11] == 0.0f && model[15] == 1.0f;
 }
 
 #ifndef MIP_TRI_MIN_WAVES_PER_SIMD
@@ -845,35 +867,43 @@ __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_
       const float4 col = a.model[(size_t)instance * 4 + q];
       model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
     }
+    const bool affine = model_is_affine(model, a.geometry_finite);
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
     if (!fits && lane == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const size_t dst_tri = (size_t)first_index / 3u;
     const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
     uint32_t survivors = 0;
 
-    // software pipeline: the index triple of step k+1 is in flight while step k gathers and tests
-    uint32_t n0 = 0, n1 = 0, n2 = 0;
-    if (lane < n_tris) {
-      const uint32_t* ip = tri_indices + (size_t)lane * 3;
-      n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
-    }
-    for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
-      const uint32_t t = t0 + lane;
-      const bool valid = t < n_tris;
-      const uint32_t i0 = n0, i1 = n1, i2 = n2;
-      if (t + 64u < n_tris) {
-        const uint32_t* ip = tri_indices + (size_t)(t + 64u) * 3;
+    // one loop per path: the choice is per command, not per step
+    auto walk = [&](auto affine_tag) {
+      constexpr bool kAffine = decltype(affine_tag)::value;
+      // software pipeline: the index triple of step k+1 is in flight while step k gathers and tests
+      uint32_t n0 = 0, n1 = 0, n2 = 0;
+      if (lane < n_tris) {
+        const uint32_t* ip = tri_indices + (size_t)lane * 3;
         n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
       }
-      const bool cull = triangle_culled(model, pv, a.vertices, (long long)vertex_offset, i0, i1, i2);
-      const bool keep = valid && !cull;
-      const unsigned long long mask = __ballot(keep);
-      if (keep && fits) {
-        uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
-        dst[0] = i0; dst[1] = i1; dst[2] = i2;
+      for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        const bool valid = t < n_tris;
+        const uint32_t i0 = n0, i1 = n1, i2 = n2;
+        if (t + 64u < n_tris) {
+          const uint32_t* ip = tri_indices + (size_t)(t + 64u) * 3;
+          n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+        }
+        float v[9];
+        triangle_fetch(a.vertices, (long long)vertex_offset, i0, i1, i2, v);
+        const bool keep = valid && !triangle_test<kAffine>(model, pv, v);
+        const unsigned long long mask = __ballot(keep);
+        if (keep && fits) {
+          uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
+          dst[0] = i0; dst[1] = i1; dst[2] = i2;
+        }
+        survivors += (uint32_t)__popcll(mask);
       }
-      survivors += (uint32_t)__popcll(mask);
-    }
+    };
+    if (affine) walk(std::true_type{});
+    else walk(std::false_type{});
     if (lane == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;  // the command's final indexCount
   }
 }
@@ -905,6 +935,7 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
       const float4 col = a.model[(size_t)instance * 4 + q];
       model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
     }
+    const bool affine = model_is_affine(model, a.geometry_finite);
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
     if (!fits && tid == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const size_t dst_tri = (size_t)first_index / 3u;
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
       const bool valid = t < n_tris;
       const uint32_t* ip = tri_indices + (size_t)(valid ? t : 0u) * 3;
       const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
-      const bool keep = valid && !triangle_culled(model, pv, a.vertices, (long long)vertex_offset, i0, i1, i2);
+      const bool keep = valid && !triangle_culled(affine, model, pv, a.vertices, (long long)vertex_offset, i0, i1, i2);
       const unsigned long long mask = __ballot(keep);
       if (lane == 0) s_wave[buf][wave] = (uint32_t)__popcll(mask);
       __syncthreads();  // one barrier per step: the totals alternate between two buffers

@@ -76,6 +76,7 @@ struct MipContext {
   uint32_t* d_indices = nullptr;
   uint32_t n_vertices = 0, n_indices = 0;
   bool have_geometry = false;
+  bool geometry_finite = false;  // every uploaded position is finite (lets the triangle stage skip exact no-ops)
   // skinned extension (mip_set_skeleton / mip_set_poses / mip_run_skinned)
   mip::JointEntry* d_joints = nullptr;
   uint32_t n_joints = 0, max_joint_depth = 0;
@@ -462,6 +463,9 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
   if (n_indices) MIP_HIP(ctx, hipMemcpy(ctx->d_indices, indices, (size_t)n_indices * 4, hipMemcpyHostToDevice));
   ctx->n_vertices = n_vertices;
   ctx->n_indices = n_indices;
+  bool finite = true;
+  for (size_t k = 0; k < (size_t)n_vertices * 3 && finite; ++k) finite = std::isfinite(vertex_xyz[k]);
+  ctx->geometry_finite = finite;
   ctx->have_geometry = true;
   return MIP_OK;
 }
@@ -611,6 +615,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       t.first_instance_base = frame->first_instance_base;
       t.error_flag = ctx->d_error;
       t.ticket = sl.d_scalars + 3;
+      t.geometry_finite = ctx->geometry_finite ? 1u : 0u;
       MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
       // The command count lives on the device; the instance count bounds it. Small frames: one

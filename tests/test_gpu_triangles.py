@@ -81,6 +81,25 @@ def test_triangle_cull_special_instances_and_bases(ra, oracle_mod):
     assert np.array_equal(got_out, want_out)
 
 
+def test_triangle_cull_with_non_finite_positions(ra, oracle_mod):
+    """Positions that are not finite switch off the affine shortcut (0 * inf is not 0): the literal
+    mat4 * vec4 chain must then reproduce the oracle, including for instances with ordinary matrices."""
+    for n in (300, 30_000):  # workgroup-per-command and wave-per-command kernels
+        s = ra.scene.make_scene(2, n=n, all_visible=(n == 300))
+        vertices, indices = ra.scene.make_geometry(s["meshes"])
+        vertices = vertices.copy()
+        vertices[10, 0] = np.inf
+        vertices[200, 1] = -np.inf
+        vertices[3000, 2] = np.nan
+        pv = ra.scene.default_pv()
+        r0 = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
+        capacity = r0["draw_index_total"] + 3
+        r, want_cmds, want_out = _oracle(oracle_mod, s, vertices, indices, pv, capacity)
+        got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity)
+        assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes(), n
+        assert np.array_equal(got_out, want_out), n
+
+
 def test_triangle_cull_reports_a_short_index_buffer(ra, oracle_mod):
     s = ra.scene.make_scene(2, n=500, all_visible=True)
     vertices, indices = ra.scene.make_geometry(s["meshes"])
