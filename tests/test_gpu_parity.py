@@ -264,6 +264,52 @@ def test_merge_draw_lists_on_device(ra, oracle_mod):
         assert e.value.code == -4
 
 
+def test_config4_ten_million_in_eight_shards(ra, oracle_mod):
+    """BASELINE configs[3] at full size on one GPU: the 10 M scene as one launch, and as 8 contiguous
+    shards of 1.25 M (each with its own draw_index base, as 8 ranks would run them) laid out like the
+    all-gather's receive buffer and merged on the device. Both must be the oracle's list, byte for byte."""
+    import torch
+
+    from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
+    from renderer_amd.sharded import chunk_stride_bytes, shard_range
+
+    s = ra.scene.make_scene(4)
+    n, world = s["n"], 8
+    assert n == 10_000_000
+    want = run_oracle(oracle_mod, s, threads=8, want=("visible_bitmap", "draw_cmds"))
+    dev = torch.device("cuda", 0)
+    with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
+        cmds = torch.zeros((want["draw_count"] + 16, 5), dtype=torch.int32, device=dev)  # exactly enough: nothing may land past the count
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        p.run_device(make_frame(s["planes"], s["cam_pos"]), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
+                     draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
+        count, index_total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+        assert count == want["draw_count"] and index_total == want["draw_index_total"]
+        assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
+        assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+        assert not cmds[count:].any()
+        del bitmap
+
+        spans = [shard_range(n, world, r) for r in range(world)]
+        assert spans[0] == (0, 1_250_000) and spans[-1][1] == n
+        cap = 400_000  # v = 0.27: ~337 k commands per shard
+        stride = chunk_stride_bytes(cap)
+        recv = torch.zeros(world * stride // 4, dtype=torch.int32, device=dev)
+        for r, (lo, hi) in enumerate(spans):
+            p.set_instances(s["pos"][lo:hi], s["rot"][lo:hi], s["scale"][lo:hi], s["mesh_id"][lo:hi])
+            base = recv.data_ptr() + r * stride
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=lo),
+                         draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4)
+        cmds.zero_()
+        p.merge_draw_lists(recv.data_ptr(), world, stride, cmds.data_ptr(), scal.data_ptr())
+        count, index_total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+        assert count == want["draw_count"] and index_total == want["draw_index_total"]
+        assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+
+
 def test_exchange_step_world_size_one(ra, oracle_mod):
     """The real frame driver (kernel -> all_gather_into_tensor over RCCL -> merge) with one rank."""
     import os

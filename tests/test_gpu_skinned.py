@@ -83,7 +83,7 @@ def _check(got, want, what):
     assert got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes(), f"{what}: commands"
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 11, 12, 13, 1000, 40_003])
+@pytest.mark.parametrize("n", [1, 2, 3, 11, 12, 13, 1000, 40_003, 256_000])
 def test_rigged_figure_scene(ra, oracle_mod, n):
     s = ra.scene.make_skinned_scene(n)
     want = oracle_mod.run_skinned(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["skeleton"], s["poses"],
