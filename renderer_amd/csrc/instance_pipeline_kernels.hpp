@@ -1110,8 +1110,8 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
 //              4 of 5 lanes idle on a humanoid);
 //   box fold   one thread per (instance, component) runs over the joints in ascending order —
 //              the oracle's order — instead of a log-step exchange of six values per lane.
-// Poses are read as five 8-byte loads per lane (40 B, lane-contiguous) and palette entries
-// written as four 16-byte stores per lane (64 B, lane-contiguous): 40 B read + 64 B written per
+// Poses are read as five 8-byte loads per lane (40 B, lane-contiguous); palette entries leave
+// through LDS so that every store instruction is 1 KiB contiguous: 40 B read + 64 B written per
 // joint. What bounds the kernel is workgroup lifetime x resident workgroups (its phases are
 // separated by barriers), so registers and LDS are kept small: 66 VGPRs, 18 KB, 7 waves per SIMD.
 constexpr uint32_t kMaxJoints = 32;
@@ -1225,12 +1225,30 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
   // ---- palette entry (mat4 per joint: 64 B per lane, lane-contiguous) ----
   float Jm[12];
   affine_mul(G, ibm, Jm);
-  if (a.palette && valid) {
-    float4* out = a.palette + ((size_t)block_first * J + pair) * 4u;
-    out[0] = make_float4(Jm[0], Jm[1], Jm[2], 0.0f);
-    out[1] = make_float4(Jm[3], Jm[4], Jm[5], 0.0f);
-    out[2] = make_float4(Jm[6], Jm[7], Jm[8], 0.0f);
-    out[3] = make_float4(Jm[9], Jm[10], Jm[11], 1.0f);
+  if (a.palette) {
+    // Through LDS, so that every store instruction of the wave is 1 KiB contiguous (four 16-byte
+    // stores per lane at a 64-byte lane stride reach 3.4 TB/s on this chip, lane-contiguous ones
+    // 6.4: tools/micro/store_pattern.hip). Staged as 3x4 in the pair's own slot — nobody else
+    // reads it after the last level — and written out as mat4: float4 q of the wave's range is
+    // column q%4 of pair q/4, with w = 0,0,0,1.
+    const uint32_t wave_inst0 = wave * ipw;
+    const uint32_t wave_insts = wave_inst0 < in_block ? (in_block - wave_inst0 < ipw ? in_block - wave_inst0 : ipw) : 0u;
+    const uint32_t wave_pair0 = wave_inst0 * J;
+    const float* wave_lds = &s_g[wave_pair0 * 12u];
+    if (valid) lds_write12(&s_g[pair * 12u], Jm);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4* out = a.palette + ((size_t)block_first * J + wave_pair0) * 4u;
+    const uint32_t quads = wave_insts * J * 4u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {
+      const uint32_t qd = lane + 64u * i;
+      if (qd < quads) {
+        const float* c = wave_lds + (qd >> 2) * 12u + (qd & 3u) * 3u;
+        out[qd] = make_float4(c[0], c[1], c[2], (qd & 3u) == 3u ? 1.0f : 0.0f);
+      }
+    }
   }
 
   // ---- this joint's share of the posed box ----
