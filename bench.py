@@ -226,6 +226,7 @@ def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_
     o = DeviceOutputs(torch, n, device)
     palette = torch.empty((n, j, 16), dtype=torch.float32, device=device)
     frame = make_frame(s["planes"], s["cam_pos"])
+    torch.cuda.synchronize()
     for _ in range(5):
         p.run_skinned(frame, palette=palette.data_ptr(), async_=True, **o.kwargs())
     p.wait()

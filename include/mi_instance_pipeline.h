@@ -50,7 +50,10 @@ extern "C" {
 
 /* ---- MipOutputs.flags ---- */
 #define MIP_OUT_HOST 0x0u   /* output pointers are host memory (copied back, synchronous) */
-#define MIP_OUT_DEVICE 0x1u /* output pointers are device memory of the context's GPU */
+#define MIP_OUT_DEVICE 0x1u /* output pointers are device memory of the context's GPU. The frame runs on the
+                              * context's own stream(s) (MipConfig.stream if given): work the caller queued on
+                              * OTHER streams for those buffers (a clear, a previous reader) is not waited for —
+                              * order it with an event / synchronize, or hand the library that stream */
 #define MIP_OUT_ASYNC 0x2u  /* with MIP_OUT_DEVICE: return after enqueue; pair with mip_wait */
 
 /* Largest LOD chain the scene loader can produce: LOD0 + 5 simplified levels

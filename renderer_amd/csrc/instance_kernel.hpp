@@ -1,0 +1,672 @@
+// instance_kernel.hpp — the gfx950 (CDNA4) kernel of the instance pipeline and the device helpers it shares.
+//
+// One fused, single-pass kernel per frame:
+//
+//   tile = 256 instances = one 256-thread workgroup (4 wave64), one instance per lane
+//   loads   : pos (12 B) + quat (16 B) + scale (4 B) + mesh id (4 B)            = 36 B
+//   compute : M = T·R·S, 8-corner world AABB, 6-plane test, LOD pick             (VALU, no FMA)
+//   stores  : mat4 through an LDS transpose so every store instruction writes
+//             1 KiB contiguous (64 B), 1 visibility bit, and — after a one-hop look-up of
+//             the tile's exclusive prefix over per-tile granules and per-group atomic
+//             accumulators of {count, Σ index_len} — the tile's surviving
+//             VkDrawIndexedIndirectCommands, coalesced, in draw_index order.
+//   Other kernels of the library live beside this file: merge_kernel.hpp (multi-GPU shard merge),
+//   triangle_kernels.hpp (row f-1), light_lists_kernel.hpp (row f-4), skinning_kernel.hpp (config 5).
+//
+// Reference semantics (paths in farnoy/renderer):
+//   src/ecs.rs:52-64 model_matrix_calculation, :138-181 aabb_calculation,
+//   src/renderer/systems/cull_pipeline.rs:99-120 coarse_culling, :534-577 cull_pass,
+//   src/renderer/helpers.rs:3-11 pick_lod, src/shaders/generate_work.comp:61-67,
+//   src/shaders/compact_draw_stream.comp:34-63.
+//
+// Arithmetic contract: IEEE binary32, every multiply and add rounded separately, in
+// the operation order nalgebra 0.29 / ncollide3d 0.32 use. This TU
+// must be compiled with -ffp-contract=off and without fast-math.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace mip {
+
+// Register budget: minimum waves per SIMD the kernel is compiled for (k workgroups of 256
+// threads per CU <=> k waves per SIMD). Overridable to build tuning variants.
+#ifndef MIP_MIN_WAVES_PER_SIMD
+#define MIP_MIN_WAVES_PER_SIMD 6
+#endif
+
+#ifndef MIP_TILE
+#define MIP_TILE 256
+#endif
+constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
+constexpr uint32_t kWaves = kTile / 64;   // wave64
+constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
+constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
+
+// Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
+// len0 = index_len[0]; len1 = index_len[1] if n_lods > 1 else index_len[0]
+// (pick_lod falls back to LOD 0 when there is only one, helpers.rs:6).
+struct alignas(16) MeshEntry {
+  float min_x, min_y, min_z;
+  uint32_t len0;
+  float max_x, max_y, max_z;
+  uint32_t len1;
+};
+
+// Per-mesh draw data, one 16-B gather for the lanes that emit a command.
+struct alignas(16) MeshDraw {
+  int32_t vertex_offset;  // ConsolidatedMeshBuffers.vertex_offsets[mesh]
+  uint32_t src_offset0;   // index_offsets[LOD 0] in the consolidated index buffer
+  uint32_t src_offset1;   // index_offsets[LOD 1] (= LOD 0's when there is only one)
+  uint32_t pad;
+};
+
+struct KernelArgs {
+  const float* pos;             // n*3
+  const float4* rot;            // n  [i,j,k,w]
+  const float* scale;           // n
+  const uint32_t* mesh_id;      // n
+  const MeshEntry* meshes;      // m
+  const MeshDraw* mesh_draw;    // m
+  float4* model;                // n*4 or null
+  uint32_t* bitmap;             // ceil(n/32) or null
+  uint32_t* cmds;               // n*5 or null
+  uint32_t* draw_count;         // with cmds
+  uint32_t* index_total;        // optional
+  uint32_t* src_index_offset;   // optional: per emitted command, where its LOD's indices start (row f-1)
+  float* world_aabb;            // n*6 or null
+  uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
+  const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
+  const float* box_override;    // n*6 or null: per-instance mesh-space box (min xyz, max xyz) that replaces the mesh table's (skinned instances)
+  unsigned long long* status0;  // level 0: one tagged granule per tile
+  unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
+  unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
+  uint32_t groups_cap;
+  uint32_t group_shift;         // log2(tiles per group), <= 6
+  uint32_t* error_flag;         // host-mapped
+  uint32_t n;
+  uint32_t n_tiles;
+  uint32_t epoch;               // 1 .. 2^31-1, unique per launch
+  uint32_t bitmap_words;
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  float planes[24];
+  float cam[3];
+#ifdef MIP_DEBUG_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
+  uint32_t debug_skip_publish_tile;  // diagnostic build only: tile index + 1 that never publishes (0 = off)
+#endif
+};
+
+#ifdef MIP_DEBUG_STAMPS
+#define MIP_STAMP(k)                                                                       \
+  do {                                                                                     \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define MIP_STAMP(k) do { } while (0)
+#endif
+
+// Largest q with sqrt_rn(q) <= 10: pick_lod tests `magnitude() > 10.0`
+// (helpers.rs:4-6) and magnitude = sqrt(norm_squared) correctly rounded, so
+// sqrt_rn(q) > 10  <=>  q > nextafter(100) (tests/test_oracle.py checks this
+// equivalence exhaustively around 100).
+constexpr float kLodDistSqThreshold = 100.00000762939453125f;  // 100 + 2^-17
+
+constexpr uint32_t kErrTimeout = 1u;
+
+// ---------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------
+
+// Inclusive prefix sum over the 64 lanes with DPP row shifts + row broadcasts (gfx9).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ---------------------------------------------------------------------------------------
+// per-instance arithmetic
+// ---------------------------------------------------------------------------------------
+
+struct Instance {
+  float m[12];      // rows 0..2 of the model matrix, column-major: m[c*3 + r]
+  uint32_t row3;    // bit c set <=> M[3][c] is NaN (otherwise it is 0,0,0,1)
+  float mins[3], maxs[3];
+};
+
+// nalgebra UnitQuaternion::to_rotation_matrix; r[row][col].
+__device__ __forceinline__ void quat_to_rotation(float i, float j, float k, float w, float (&r)[3][3]) {
+  const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+  const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+  const float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+  r[0][0] = ww + ii - jj - kk; r[0][1] = ij - wk;           r[0][2] = wj + ik;
+  r[1][0] = wk + ij;           r[1][1] = ww - ii + jj - kk; r[1][2] = jk - wi;
+  r[2][0] = ik - wj;           r[2][1] = wi + jk;           r[2][2] = ww - ii - jj + kk;
+}
+
+__device__ __forceinline__ void fold_corner(const float (&v)[3], float (&lo)[3], float (&hi)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = fminf(lo[a], v[a]);  // f32::min: a NaN operand is ignored
+    hi[a] = fmaxf(hi[a], v[a]);
+  }
+}
+
+__device__ __forceinline__ void finish_aabb(const float (&lo)[3], const float (&hi)[3], Instance& o) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float centre = (hi[a] + lo[a]) / 2.0f;
+    const float half = (hi[a] - lo[a]) / 2.0f;
+    o.mins[a] = centre - half;  // AABB::from_half_extents
+    o.maxs[a] = centre + half;
+  }
+}
+
+// Fast path, exact whenever the 9 rotation entries, the position and the scale are all
+// finite (and the mesh box is, which mip_set_mesh_table enforces): then every product
+// with a 0 or 1 entry of T, S and the homogeneous row/column is exact, (T·R)·S collapses
+// to M[r][c] = fl(R[r][c]·s), M[:,3] = (p,1), M[3,:] = (0,0,0,1), and w = 1 for every
+// corner, so `/ w` is the identity.
+__device__ __forceinline__ void model_fast(const float (&r)[3][3], float px, float py, float pz, float s, Instance& o) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) o.m[c * 3 + rr] = r[rr][c] * s;
+  o.m[9] = px; o.m[10] = py; o.m[11] = pz;
+  o.row3 = 0;
+}
+
+__device__ __forceinline__ void instance_fast(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+  model_fast(r, px, py, pz, s, o);
+  float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+  const float bx[2] = {mb.min_x, mb.max_x}, by[2] = {mb.min_y, mb.max_y}, bz[2] = {mb.min_z, mb.max_z};
+  // corner order of src/ecs.rs:149-160: x toggles fastest, then z, then y
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float x = bx[c & 1], z = bz[(c >> 1) & 1], y = by[(c >> 2) & 1];
+    float v[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)  // gemv as column axpys: ((m0 x + m1 y) + m2 z) + m3·1
+      v[rr] = o.m[0 * 3 + rr] * x + o.m[1 * 3 + rr] * y + o.m[2 * 3 + rr] * z + o.m[9 + rr];
+    fold_corner(v, lo, hi);
+  }
+  finish_aabb(lo, hi, o);
+}
+
+// nalgebra gemv (alpha = 1, beta = 0): column axpys left to right.
+__device__ __forceinline__ void gemv4(const float (&a)[16], const float (&x)[4], float (&y)[4]) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) y[rr] = a[rr] * x[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) y[rr] = a[k * 4 + rr] * x[k] + y[rr];
+}
+
+__device__ __forceinline__ void gemm4(const float (&a)[16], const float (&b)[16], float (&out)[16]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float x[4] = {b[c * 4 + 0], b[c * 4 + 1], b[c * 4 + 2], b[c * 4 + 3]};
+    float y[4];
+    gemv4(a, x, y);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) out[c * 4 + rr] = y[rr];
+  }
+}
+
+// General path: the reference chain performed literally — translation(p) *
+// rot.to_homogeneous() * scaling(s) as two full 4x4 products, full mat4*vec4 per corner
+// and the divide by w — so non-finite inputs poison exactly the entries they poison in
+// the reference. Taken by a whole wave when any of its lanes fails the finite test.
+__device__ __forceinline__ void model_general(const float (&r)[3][3], float px, float py, float pz, float s, Instance& o,
+                                              float (&m)[16]) {
+  float t[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, px, py, pz, 1};
+  float rh[16] = {r[0][0], r[1][0], r[2][0], 0, r[0][1], r[1][1], r[2][1], 0,
+                  r[0][2], r[1][2], r[2][2], 0, 0, 0, 0, 1};
+  float sc[16] = {s, 0, 0, 0, 0, s, 0, 0, 0, 0, s, 0, 0, 0, 0, 1};
+  float tr[16];
+  gemm4(t, rh, tr);
+  gemm4(tr, sc, m);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) o.m[c * 3 + rr] = m[c * 4 + rr];
+  o.row3 = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o.row3 |= (m[c * 4 + 3] != m[c * 4 + 3]) ? (1u << c) : 0u;
+}
+
+__device__ __forceinline__ void instance_general(const float (&r)[3][3], float px, float py, float pz,
+                                              float s, const MeshEntry& mb, Instance& o) {
+  float m[16];
+  model_general(r, px, py, pz, s, o, m);
+  float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
+  float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {  // unrolled so the corner selects stay in registers
+    const float vh[4] = {(c & 1) ? mb.max_x : mb.min_x, (c & 4) ? mb.max_y : mb.min_y,
+                         (c & 2) ? mb.max_z : mb.min_z, 1.0f};
+    float tv[4];
+    gemv4(m, vh, tv);
+    const float v[3] = {tv[0] / tv[3], tv[1] / tv[3], tv[2] / tv[3]};
+    fold_corner(v, lo, hi);
+  }
+  finish_aabb(lo, hi, o);
+}
+
+// src/renderer/systems/cull_pipeline.rs:108-119. Planes are wave-uniform (SGPRs).
+__device__ __forceinline__ bool coarse_culled(const Instance& o, const float (&planes)[24]) {
+  float h[3], c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    h[a] = (o.maxs[a] - o.mins[a]) * 0.5f;  // AABB::half_extents
+    c[a] = (o.mins[a] + o.maxs[a]) * 0.5f;  // AABB::center
+  }
+  bool outside = false;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const float nx = planes[p * 4 + 0], ny = planes[p * 4 + 1], nz = planes[p * 4 + 2], d = planes[p * 4 + 3];
+    const float e = h[0] * fabsf(nx) + h[1] * fabsf(ny) + h[2] * fabsf(nz);  // 3-wide dot: (a+b)+c
+    float a0 = nx * c[0];
+    float a1 = ny * c[1];
+    const float a2 = nz * c[2];
+    const float a3 = d;  // d * 1
+    a0 += a2;            // 4-wide dot: (a0+a2) + (a1+a3)
+    a1 += a3;
+    const float sd = a0 + a1;
+    outside = outside || (sd - e > 0.0f);  // the reference's early break changes nothing
+  }
+  return outside;
+}
+
+// ---------------------------------------------------------------------------------------
+// cross-tile prefix: one hop, no chains
+// ---------------------------------------------------------------------------------------
+// A tile's exclusive prefix (count, Σ index_len) over all earlier tiles is assembled from
+// words that every tile publishes as soon as it knows its own aggregate — it never depends
+// on another tile having finished its own look-up, so the wait is one memory round trip
+// after the slowest predecessor has published (measured: a hop costs ~1 µs on an idle
+// chip and ~3 µs behind streaming traffic, so chains of hops are what must be avoided).
+//
+//   level 0  status0[tile]   ONE 8-byte granule {Σ index_len : 32 | tag : 23 | count : 9},
+//                            written by one relaxed agent-scope atomic store
+//                            (global_store_dwordx2 sc1); tag = launch epoch (never 0), so
+//                            the array is never cleared between launches.
+//   level 1  acc1[parity][g] one 64-bit accumulator per group of 2^group_shift consecutive
+//                            tiles, 256 B apart (packed words put every tile's reads and
+//                            the atomics on one or two memory channels: measured 5x
+//                            slower); every tile of the group adds
+//                            {Σ index_len : 32 | arrivals : 12 | count : 20} with one
+//                            no-return agent-scope atomic add (executes at the memory side).
+//                            A group is complete when arrivals == tiles per group. The
+//                            buffer of the other parity is zeroed for the next launch by
+//                            the first tile of each group; the host clears everything
+//                            whenever the instance count changes or the tag wraps.
+//
+//            start1[g]       {epoch : 32 | count : 32} {epoch : 32 | Σ index_len : 32}: the exclusive
+//                            prefix at the start of group g, published by the group's first
+//                            tile when it has resolved its own prefix (a by-product).
+//
+//   prefix(tile) = start1[g_lo] + Σ acc1[g_lo .. g-1] + Σ status0[first tile of g .. tile-1],
+//   g_lo = max(0, g - 64)
+//
+// No payload is handed off behind these words (every tile writes its own commands), so no
+// release/acquire fence is involved; readers use relaxed agent-scope atomic loads (sc1).
+
+constexpr uint32_t kAccCountBits = 20;  // the 12 bits above it count the tiles that have added
+// Accumulators live 256 B apart: every tile reads every earlier group's word, and packed
+// words would put all of that traffic (and the atomics) on one or two memory channels.
+constexpr uint32_t kAccStrideWords = 32;
+constexpr uint32_t kTileCountBits = kTile <= 256 ? 9 : (kTile <= 512 ? 10 : 11);
+constexpr uint32_t kTagBits = 32 - kTileCountBits;
+constexpr uint32_t kMaxEpoch = (1u << kTagBits) - 1u;
+static_assert(kTile < (1u << kTileCountBits), "tile count must fit its field");
+
+__device__ __forceinline__ unsigned long long status_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ONE lane of the tile once its aggregate is known.
+__device__ __forceinline__ void publish_aggregate(const KernelArgs& a, uint32_t tile, uint32_t count, uint32_t sum) {
+  const unsigned long long granule = ((unsigned long long)sum << 32) | ((unsigned long long)a.epoch << kTileCountBits) | count;
+  __hip_atomic_store(&a.status0[tile], granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t group = tile >> a.group_shift;
+  const uint32_t parity = a.epoch & 1u;
+  const unsigned long long add = ((unsigned long long)sum << 32) | (1ull << kAccCountBits) | count;
+  (void)__hip_atomic_fetch_add(&a.acc1[((size_t)parity * a.groups_cap + group) * kAccStrideWords], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((tile & ((1u << a.group_shift) - 1u)) == 0u)  // first tile of the group: reset the next launch's word
+    __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz realtime counter
+constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
+
+// Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`:
+//   prefix = start1[g_lo]  +  Σ acc1[g_lo .. g-1]  +  Σ status0[first tile of g .. tile-1]
+// with g_lo = max(0, g - 64). start1[g] (the exclusive prefix at the start of group g) is
+// published for free by the first tile of group g once it has resolved its own prefix; the
+// entry read here is 64 groups = thousands of tiles back, i.e. long resolved, so the look-up
+// stays ONE round of <= 63 + 64 + 1 words for any N (without it every tile would read every
+// earlier group: quadratic, measured +100 us at 10 M instances).
+__device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t tile, uint32_t lane,
+                                               uint32_t& base_count, uint32_t& base_sum) {
+  const uint32_t group = tile >> a.group_shift;
+  const uint32_t group_first = group << a.group_shift;
+  const uint32_t r = tile - group_first;  // earlier tiles of the own group (< 64)
+  const uint32_t per_group = 1u << a.group_shift;
+  const uint32_t g_lo = group > kLevel1Window ? group - kLevel1Window : 0u;
+  const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  bool ok = true;
+
+  // level 0: lane l < r reads the aggregate of tile group_first + l
+  const bool v0 = lane < r;
+  const unsigned long long* e0 = &a.status0[group_first + (v0 ? lane : 0u)];
+  // level 1: lane l reads the accumulator of group g_lo + l
+  const bool v1 = g_lo + lane < group;
+  const unsigned long long* e1 = &acc[(size_t)(g_lo + (v1 ? lane : 0u)) * kAccStrideWords];
+  // far prefix: lane 0 reads the two granules of start1[g_lo]
+  const bool v2 = g_lo > 0u && lane == 0u;
+  const unsigned long long* e2 = &a.start1[2 * (size_t)g_lo];
+
+  bool ready0 = !v0, ready1 = !v1, ready2 = !v2;
+  uint32_t c = 0, s = 0;
+  for (;;) {
+    if (!ready0) {
+      const unsigned long long g = status_load(e0);
+      if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
+        ready0 = true;
+        c += (uint32_t)g & ((1u << kTileCountBits) - 1u);
+        s += (uint32_t)(g >> 32);
+      }
+    }
+    if (!ready1) {
+      const unsigned long long w = status_load(e1);
+      if (((uint32_t)w >> kAccCountBits) == per_group) {  // every tile of that group has added
+        ready1 = true;
+        c += (uint32_t)w & ((1u << kAccCountBits) - 1u);
+        s += (uint32_t)(w >> 32);
+      }
+    }
+    if (!ready2) {
+      const unsigned long long pc = status_load(e2), ps = status_load(e2 + 1);
+      if ((uint32_t)(pc >> 32) == a.epoch && (uint32_t)(ps >> 32) == a.epoch) {
+        ready2 = true;
+        c += (uint32_t)pc;
+        s += (uint32_t)ps;
+      }
+    }
+    const bool all = ready0 && ready1 && ready2;
+#ifdef MIP_DEBUG_STAMPS
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
+#endif
+    if (__all(all)) break;
+    if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
+      ok = false;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (ok) {
+    base_count = wave_sum(c);
+    base_sum = wave_sum(s);
+    if (r == 0u && group > 0u && lane == 0u) {  // first tile of a group: publish the group's start
+      unsigned long long* p = &a.start1[2 * (size_t)group];
+      __hip_atomic_store(p, ((unsigned long long)a.epoch << 32) | base_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p + 1, ((unsigned long long)a.epoch << 32) | base_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    if (lane == 0) __hip_atomic_store(a.error_flag, kErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    base_count = 0;
+    base_sum = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pipeline_kernel(const KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
+  __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
+  // The tile's commands (5 KB) reuse the staging area of waves 1-3 (9 KB) once those waves have
+  // stored their matrices: 13.6 KB of LDS per workgroup instead of 18.5 KB, so that more
+  // workgroups whose wave 0 is still waiting for its prefix fit beside the running ones.
+  uint32_t* const s_cmd = reinterpret_cast<uint32_t*>(&s_mat[64 * 12]);
+  static_assert((kTile - 64) * 12 >= kTile * kCmdLdsWords, "commands must fit the staging area of waves 1-3");
+  __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tile_first = tile * kTile;
+  const uint32_t i = tile_first + tid;
+  const bool active = i < a.n;
+  const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
+  MIP_STAMP(0);
+
+  // ---- loads: 36 B per instance ----
+  const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
+  const float4 q = a.rot[il];
+  const float sc = a.scale[il];
+  const uint32_t mesh = a.mesh_id[il];
+  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
+  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  MeshEntry mb;
+  mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
+  mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
+
+  // ---- model matrix + world AABB ----
+  float r[3][3];
+  quat_to_rotation(q.x, q.y, q.z, q.w, r);
+  // Finite test for the fast path: a sum of magnitudes is NaN/inf as soon as one term is
+  // (or the sum overflows — then the general path, which is exact for everything, runs).
+  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  if (a.box_override) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
+    const float2* b2 = reinterpret_cast<const float2*>(a.box_override + (size_t)il * 6);
+    const float2 b01 = b2[0], b23 = b2[1], b45 = b2[2];
+    mb.min_x = b01.x; mb.min_y = b01.y; mb.min_z = b23.x;
+    mb.max_x = b23.y; mb.max_y = b45.x; mb.max_z = b45.y;
+    // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
+    mag += fabsf(b01.x) + fabsf(b01.y) + fabsf(b23.x) + fabsf(b23.y) + fabsf(b45.x) + fabsf(b45.y);
+  }
+  const bool all_finite = mag < 3.0e38f;
+  Instance inst;
+  if (__builtin_expect(__any(!all_finite), 0)) {
+    instance_general(r, px, py, pz, sc, mb, inst);
+  } else {
+    instance_fast(r, px, py, pz, sc, mb, inst);
+  }
+
+  MIP_STAMP(1);
+  // ---- frustum test, LOD, command length ----
+  const bool culled = coarse_culled(inst, a.planes);
+  const bool visible = active && !culled;
+  const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
+  const float dist_sq = dx * dx + dy * dy + dz * dz;
+  const uint32_t len = (dist_sq > kLodDistSqThreshold) ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
+  const bool keep = visible && len > 0u;  // compact_draw_stream.comp:41 `indexCount > 0`
+  const uint32_t len_vis = visible ? len : 0u;
+
+  // ---- wave-level compaction offsets ----
+  const unsigned long long keep_mask = __ballot(keep);
+  const unsigned long long vis_mask = __ballot(visible);
+  const uint32_t rank_in_wave = lanes_below(keep_mask);
+  const uint32_t incl_sum = wave_inclusive_scan(len_vis);
+  if (lane == 63u) {
+    s_wave_count[wave] = (uint32_t)__popcll(keep_mask);
+    s_wave_sum[wave] = incl_sum;
+  }
+
+  // ---- stage the matrix rows for the transposed store ----
+  if (a.model || a.tlas_instances) {
+    float4* dst = reinterpret_cast<float4*>(&s_mat[tid * 12]);
+    dst[0] = make_float4(inst.m[0], inst.m[1], inst.m[2], inst.m[3]);
+    dst[1] = make_float4(inst.m[4], inst.m[5], inst.m[6], inst.m[7]);
+    dst[2] = make_float4(inst.m[8], inst.m[9], inst.m[10], inst.m[11]);
+    s_row3[tid] = inst.row3 | (mesh << 4);  // NaN bits of row 3 + the mesh id (for the TLAS rows)
+  }
+  __syncthreads();
+
+  uint32_t wave_off_count = 0, wave_off_sum = 0, tile_count = 0, tile_sum = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kWaves; ++w) {
+    const uint32_t wc = s_wave_count[w], ws = s_wave_sum[w];
+    if (w < wave) { wave_off_count += wc; wave_off_sum += ws; }
+    tile_count += wc;
+    tile_sum += ws;
+  }
+
+  const bool want_cmds = a.cmds != nullptr;
+#ifdef MIP_DEBUG_STAMPS
+  // fault injection (diagnostic build only): one tile never publishes, so every later tile's
+  // bounded wait must expire and the launch must end with MIP_ERR_TIMEOUT instead of hanging
+  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
+#else
+  const bool skip_publish = false;
+#endif
+  if (want_cmds && tid == 0 && !skip_publish) publish_aggregate(a, tile, tile_count, tile_sum);
+  MIP_STAMP(2);
+
+  // Bulk stores of this wave: matrices, visibility words, optional AABBs. Wave 0 issues
+  // them only AFTER it has resolved the tile prefix: loads return in order with stores
+  // (vmcnt counts both), so a poll behind 4 KiB of stores would wait for their acks.
+  auto bulk_stores = [&]() {
+    // ---- model matrices: 4 store instructions per wave, each 1 KiB contiguous ----
+    if (a.model) {
+      const uint32_t wave_first = wave * 64u;
+      const float* src = &s_mat[wave_first * 12];
+      float4* out = a.model + ((size_t)tile_first + wave_first) * 4;
+      const uint32_t col = lane & 3u;
+  #pragma unroll
+      for (uint32_t s4 = 0; s4 < 4; ++s4) {
+        const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
+        const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
+        const uint32_t bits = s_row3[wave_first + local] & 15u;
+        float w = (col == 3u) ? 1.0f : 0.0f;
+        if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
+        if (tile_first + wave_first + local < a.n)
+          out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
+      }
+    }
+
+    // ---- optional TLAS instance rows (acceleration_strucures.rs:419-451), same transposed store ----
+    // VkAccelerationStructureInstanceKHR = { 3x4 row-major transform = rows 0..2 of M,
+    //   instanceCustomIndex:24 = draw_index | mask:8 = 0xFF, sbtOffset:24 = 0 | flags:8 =
+    //   TRIANGLE_FACING_CULL_DISABLE, BLAS device address }, for EVERY instance (visible or not).
+    if (a.tlas_instances) {
+      const uint32_t wave_first = wave * 64u;
+      const float* src = &s_mat[wave_first * 12];
+      uint4* out = a.tlas_instances + ((size_t)tile_first + wave_first) * 4;
+      const uint32_t q = lane & 3u;
+  #pragma unroll
+      for (uint32_t s4 = 0; s4 < 4; ++s4) {
+        const uint32_t local = 16u * s4 + (lane >> 2);
+        const uint32_t draw = tile_first + wave_first + local;
+        uint4 v;
+        if (q < 3u) {  // row q: one element of each staged column
+          const float* col = src + local * 12u + q;
+          v = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[3]), __float_as_uint(col[6]), __float_as_uint(col[9]));
+        } else {
+          const uint32_t mesh_of = s_row3[wave_first + local] >> 4;
+          const unsigned long long blas = (draw < a.n && a.blas_address) ? a.blas_address[mesh_of] : 0ull;
+          v = make_uint4(((a.first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
+                         (uint32_t)blas, (uint32_t)(blas >> 32));
+        }
+        if (draw < a.n) out[64u * s4 + lane] = v;
+      }
+    }
+
+    // ---- visibility bitmap: one 64-bit ballot per wave, written as two words ----
+    if (a.bitmap && lane < 2u) {
+      const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
+      if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
+    }
+
+    // ---- optional world AABB (mins, maxs) as the ECS component holds it ----
+    if (a.world_aabb && active) {
+      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
+      o2[0] = make_float2(inst.mins[0], inst.mins[1]);
+      o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
+      o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
+    }
+
+  };
+
+  if (!want_cmds) {
+    bulk_stores();
+    return;
+  }
+
+  if (wave != 0) bulk_stores();
+  __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
+
+  // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
+  if (keep) {
+    const bool far_lod = dist_sq > kLodDistSqThreshold;
+    const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
+    uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
+    c[0] = len;                                               // indexCount
+    c[1] = 1u;                                                // instanceCount, generate_work.comp:63
+    c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
+    c[3] = md.x;                                              // vertexOffset, :66
+    c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
+    c[5] = far_lod ? md.z : md.y;                             // push constant indexOffset, cull_pipeline.rs:552
+  }
+  __syncthreads();  // s_cmd complete
+  MIP_STAMP(3);
+
+  // Waves 1-3 are finished: they exit and free their registers and wave slots for the next
+  // workgroup while wave 0 alone waits for the tile's prefix and copies the commands out.
+  if (wave != 0) return;
+
+  // ---- exclusive prefix over the earlier tiles, before any bulk store of this wave ----
+  uint32_t base_count = 0, base_sum = 0;
+  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+  if (lane == 0 && tile == a.n_tiles - 1u) {
+    *a.draw_count = base_count + tile_count;
+    if (a.index_total) *a.index_total = base_sum + tile_sum;
+  }
+  MIP_STAMP(4);
+
+  // ---- coalesced copy-out of the tile's commands ----
+  const uint32_t first_index_add = base_sum + a.first_index_base;
+  uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
+  const uint32_t words = tile_count * kCmdWords;
+  for (uint32_t j = lane; j < words; j += 64u) {
+    const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
+    uint32_t v = s_cmd[k * kCmdLdsWords + f];
+    if (f == 2u) v += first_index_add;
+    out[j] = v;
+  }
+  if (a.src_index_offset)
+    for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
+  bulk_stores();
+  MIP_STAMP(5);
+}
+
+}  // namespace mip

@@ -389,6 +389,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
       for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
     MIP_HIP(ctx, hipEventCreate(&ctx->ev0));
     MIP_HIP(ctx, hipEventCreate(&ctx->ev1));
+    // the memsets above ran on the null stream, which the slots' non-blocking streams do not wait for
+    MIP_HIP(ctx, hipDeviceSynchronize());
     return MIP_OK;
   }();
   if (rc != MIP_OK) {
@@ -427,8 +429,9 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (m) {
-    MIP_HIP(ctx, hipMemcpy(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice));
-    MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_draw, draw.data(), m * sizeof(mip::MeshDraw), hipMemcpyHostToDevice));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice, ctx->stream));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_draw, draw.data(), m * sizeof(mip::MeshDraw), hipMemcpyHostToDevice, ctx->stream));
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sources are locals
   }
   ctx->m = m;
   ctx->have_meshes = true;
@@ -442,7 +445,8 @@ int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint3
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (!ctx->d_blas) MIP_HIP(ctx, hipMalloc(&ctx->d_blas, (size_t)(ctx->max_meshes ? ctx->max_meshes : 1) * 8));
-  if (m) MIP_HIP(ctx, hipMemcpy(ctx->d_blas, addresses, (size_t)m * 8, hipMemcpyHostToDevice));
+  if (m) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_blas, addresses, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // uploads are stream-ordered copies: finished before any slot launches again
   return MIP_OK;
 }
 
@@ -459,8 +463,9 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
   ctx->have_geometry = false;
   MIP_HIP(ctx, hipMalloc(&ctx->d_vertices, (size_t)(n_vertices ? n_vertices : 1) * 12));
   MIP_HIP(ctx, hipMalloc(&ctx->d_indices, (size_t)(n_indices ? n_indices : 1) * 4));
-  if (n_vertices) MIP_HIP(ctx, hipMemcpy(ctx->d_vertices, vertex_xyz, (size_t)n_vertices * 12, hipMemcpyHostToDevice));
-  if (n_indices) MIP_HIP(ctx, hipMemcpy(ctx->d_indices, indices, (size_t)n_indices * 4, hipMemcpyHostToDevice));
+  if (n_vertices) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_vertices, vertex_xyz, (size_t)n_vertices * 12, hipMemcpyHostToDevice, ctx->stream));
+  if (n_indices) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_indices, indices, (size_t)n_indices * 4, hipMemcpyHostToDevice, ctx->stream));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // uploads are stream-ordered copies: finished before any slot launches again
   ctx->n_vertices = n_vertices;
   ctx->n_indices = n_indices;
   bool finite = true;
@@ -478,10 +483,11 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (n) {
-    MIP_HIP(ctx, hipMemcpy(ctx->d_pos, pos, (size_t)n * 12, kind));
-    MIP_HIP(ctx, hipMemcpy(ctx->d_rot, rot, (size_t)n * 16, kind));
-    MIP_HIP(ctx, hipMemcpy(ctx->d_scale, scale, (size_t)n * 4, kind));
-    MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_pos, pos, (size_t)n * 12, kind, ctx->stream));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_rot, rot, (size_t)n * 16, kind, ctx->stream));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_scale, scale, (size_t)n * 4, kind, ctx->stream));
+    MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind, ctx->stream));
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // stream-ordered copies: finished before any slot launches again
   }
   if (n != ctx->n) {
     for (auto& sl : ctx->slots) sl.status_dirty = true;  // tile/group geometry changes with n
@@ -515,10 +521,11 @@ int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, co
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (count) {
-    if (pos_xyz) MIP_HIP(ctx, hipMemcpy(ctx->d_pos + (size_t)first * 3, pos_xyz, (size_t)count * 12, hipMemcpyHostToDevice));
-    if (rot_ijkw) MIP_HIP(ctx, hipMemcpy(ctx->d_rot + first, rot_ijkw, (size_t)count * 16, hipMemcpyHostToDevice));
-    if (scale) MIP_HIP(ctx, hipMemcpy(ctx->d_scale + first, scale, (size_t)count * 4, hipMemcpyHostToDevice));
-    if (mesh_id) MIP_HIP(ctx, hipMemcpy(ctx->d_mesh_id + first, mesh_id, (size_t)count * 4, hipMemcpyHostToDevice));
+    if (pos_xyz) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_pos + (size_t)first * 3, pos_xyz, (size_t)count * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (rot_ijkw) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_rot + first, rot_ijkw, (size_t)count * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (scale) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_scale + first, scale, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (mesh_id) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_id + first, mesh_id, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   return MIP_OK;
 }
@@ -566,7 +573,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     a.box_override = ctx->d_skin_box;
   }
 
-  // Cross-tile prefix state (see instance_pipeline_kernels.hpp): a fresh tag per launch marks
+  // Cross-tile prefix state (see instance_kernel.hpp): a fresh tag per launch marks
   // the level-0 words; the level-1 accumulators alternate between two buffers by tag parity,
   // the kernel zeroing the other one. Launches without draw commands do not touch the state.
   if (a.cmds && n) {
@@ -850,7 +857,8 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (!ctx->d_joints) MIP_HIP(ctx, hipMalloc(&ctx->d_joints, sizeof(mip::JointEntry) * MIP_MAX_JOINTS));
-  MIP_HIP(ctx, hipMemcpy(ctx->d_joints, joints.data(), sizeof(mip::JointEntry) * n_joints, hipMemcpyHostToDevice));
+  MIP_HIP(ctx, hipMemcpyAsync(ctx->d_joints, joints.data(), sizeof(mip::JointEntry) * n_joints, hipMemcpyHostToDevice, ctx->stream));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_joints != ctx->n_joints) {  // the pose layout depends on the joint count
     ctx->d_poses = nullptr;
     ctx->poses_n = 0;
@@ -875,7 +883,8 @@ int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_
     if (!ctx->d_poses_owned)
       MIP_HIP(ctx, hipMalloc(&ctx->d_poses_owned, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * MIP_MAX_JOINTS * MIP_POSE_FLOATS * 4));
     if (n)
-      MIP_HIP(ctx, hipMemcpy(ctx->d_poses_owned, joint_trs, (size_t)n * ctx->n_joints * MIP_POSE_FLOATS * 4, hipMemcpyHostToDevice));
+      MIP_HIP(ctx, hipMemcpyAsync(ctx->d_poses_owned, joint_trs, (size_t)n * ctx->n_joints * MIP_POSE_FLOATS * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n) MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->d_poses = ctx->d_poses_owned;
   }
   ctx->poses_n = n;
@@ -1010,8 +1019,9 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
   const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
   const size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;
   MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
-  MIP_HIP(ctx, hipMemset(ctx->d_send, 0, stride));
+  MIP_HIP(ctx, hipMemsetAsync(ctx->d_send, 0, stride, ctx->stream));
   MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MIP_OK;
 }
 

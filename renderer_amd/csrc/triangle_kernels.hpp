@@ -1,0 +1,298 @@
+// triangle_kernels.hpp — row f-1: per-triangle cull + index-stream append, and the re-compaction after it (gfx950).
+#pragma once
+
+#include "instance_kernel.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mip {
+
+// ---------------------------------------------------------------------------------------
+// row f-1: per-triangle cull + index-stream append (src/shaders/generate_work.comp:68-200)
+// ---------------------------------------------------------------------------------------
+// The reference records one dispatch per visible instance (cull_pipeline.rs:536-577). Here
+// one launch walks the compacted command list: ONE WAVE PER COMMAND, 64 triangles per
+// step, the running survivor count in a register — no inter-wave communication, and the
+// surviving triangles keep their mesh order (the stable member of the reference's
+// outcome set; its workgroups append in atomicAdd arrival order, :176-186).
+// Arithmetic: clip = pv * (model * vec4(v,1)) as column combinations left to right, no
+// FMA; back-face = determinant of the xyw columns > 0; x/y NDC rejection after a true
+// divide — exactly what the oracle (orc_cull_triangles) fixes where GLSL leaves it open.
+
+struct TriangleArgs {
+  uint32_t* cmds;                 // compacted commands of the instance kernel; indexCount is rewritten
+  const uint32_t* count;          // number of commands (device)
+  const uint32_t* src_index_offset;
+  const float4* model;            // n x mat4 of the same frame
+  const float* vertices;          // consolidated positions, packed vec3
+  const uint32_t* indices;        // consolidated indices
+  uint32_t* out_indices;          // culled index stream (uvec3 out_index_buffer[])
+  unsigned long long capacity;    // in indices
+  uint32_t first_instance_base;
+  uint32_t* error_flag;
+  uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
+  uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
+  float pv[16];
+};
+
+constexpr uint32_t kErrIndexOverflow = 4u;
+
+__device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x, float y, float z, float w, float (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = m[0 * 4 + r] * x + m[1 * 4 + r] * y + m[2 * 4 + r] * z + m[3 * 4 + r] * w;
+}
+
+// The three positions of a triangle (packed vec3 each).
+__device__ __forceinline__ void triangle_fetch(const float* vertices, long long vertex_offset, uint32_t i0, uint32_t i1,
+                                               uint32_t i2, float (&v)[9]) {
+  const uint32_t ix[3] = {i0, i1, i2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float* p = vertices + (vertex_offset + (long long)ix[k]) * 3;
+    v[k * 3 + 0] = p[0]; v[k * 3 + 1] = p[1]; v[k * 3 + 2] = p[2];
+  }
+}
+
+// One triangle of generate_work.comp:132-155: true = culled (back-facing or beyond one x/y bound).
+// kAffine: the caller has checked that row 3 of `model` is (0,0,0,1) and that the geometry holds
+// only finite positions. Then world.w = ((0*x + 0*y) + 0*z) + 1 is exactly 1 and pv[:,3] * world.w
+// is exactly pv[:,3], so that row and those four products are skipped: same bits, 126 instead
+// of 156 flops per triangle.
+template <bool kAffine>
+__device__ __forceinline__ bool triangle_test(const float (&model)[16], const float (&pv)[16], const float (&v)[9]) {
+  float clip[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if constexpr (kAffine) {
+      const float x = v[k * 3 + 0], y = v[k * 3 + 1], z = v[k * 3 + 2];
+      float world[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) world[r] = model[0 * 4 + r] * x + model[1 * 4 + r] * y + model[2 * 4 + r] * z + model[3 * 4 + r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) clip[k][r] = pv[0 * 4 + r] * world[0] + pv[1 * 4 + r] * world[1] + pv[2 * 4 + r] * world[2] + pv[3 * 4 + r];
+    } else {
+      float world[4];
+      glsl_mat4_mul_vec4(model, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], 1.0f, world);
+      glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
+    }
+  }
+  const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
+  const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][3];
+  const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][3];
+  const float det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) + a20 * (a01 * a12 - a11 * a02);
+  bool cull = det > 0.0f;
+  // ndc = clip.xy / clip.w compared with -1 and 1 (generate_work.comp:143-155), without dividing:
+  // for floats x, w the correctly rounded quotient q = RN(x / w) satisfies
+  //     q > 1  <=>  x*sgn(w) > |w|        q < -1  <=>  x*sgn(w) < -|w|
+  // because x*sgn(w) > |w| puts x/w at least one ulp(w)/|w| >= 2^-23 above 1, past the rounding
+  // boundary 1 + 2^-24, and x*sgn(w) <= |w| gives x/w <= 1. It also holds at w = +-0 (q = +-inf by
+  // the signs, NaN for 0/0), for infinities and NaNs (every comparison false), and for subnormals
+  // (tests/test_oracle.py::test_ndc_comparison_without_division checks it against real divisions).
+  // The six correctly rounded divides were 60 of the 197 VALU instructions of a step.
+  bool xl = true, xg = true, yl = true, yg = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t sw = __float_as_uint(clip[k][3]) & 0x80000000u;
+    const float w = fabsf(clip[k][3]);
+    const float x = __uint_as_float(__float_as_uint(clip[k][0]) ^ sw);
+    const float y = __uint_as_float(__float_as_uint(clip[k][1]) ^ sw);
+    xl = xl && (x < -w);
+    xg = xg && (x > w);
+    yl = yl && (y < -w);
+    yg = yg && (y > w);
+  }
+  return cull || xl || xg || yl || yg;
+}
+
+__device__ __forceinline__ bool triangle_culled(bool affine, const float (&model)[16], const float (&pv)[16], const float* vertices,
+                                                long long vertex_offset, uint32_t i0, uint32_t i1, uint32_t i2) {
+  float v[9];
+  triangle_fetch(vertices, vertex_offset, i0, i1, i2, v);
+  return affine ? triangle_test<true>(model, pv, v) : triangle_test<false>(model, pv, v);  // wave-uniform
+}
+
+// Wave-uniform: may this command's triangles take the affine path?
+__device__ __forceinline__ bool model_is_affine(const float (&model)[16], uint32_t geometry_finite) {
+  return geometry_finite != 0u && model[3] == 0.0f && model[7] == 0.0f && model[11] == 0.0f && model[15] == 1.0f;
+}
+
+#ifndef MIP_TRI_MIN_WAVES_PER_SIMD
+#define MIP_TRI_MIN_WAVES_PER_SIMD 4
+#endif
+
+__global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t count = *a.count;
+  float pv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
+
+  // Commands differ 1000x in triangle count (LODs, mixed meshes): waves pull the next command
+  // from a ticket counter instead of striding over the list (measured: static striding left a
+  // third of the waves idle at 5 k commands). The counter is zeroed by the host per launch.
+  // Every lane takes part in the add (lane 0 adds 1, the others 0: the compiler folds the wave's
+  // adds into one atomic), so there is no divergent branch around it, and the loop is bounded
+  // by the command count whatever the counter holds.
+  for (uint32_t pulled = 0; pulled <= count; ++pulled) {
+    const uint32_t old = atomicAdd(a.ticket, lane == 0u ? 1u : 0u);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);  // wave-uniform: scalar loads below
+    if (c >= count) break;
+
+    const uint32_t index_count = a.cmds[c * kCmdWords + 0];
+    const uint32_t first_index = a.cmds[c * kCmdWords + 2];
+    const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
+    const uint32_t instance = a.cmds[c * kCmdWords + 4] - a.first_instance_base;
+    const uint32_t src_tri = a.src_index_offset[c] / 3u;  // index_buffer[indexOffset / 3 + id]
+    const uint32_t n_tris = index_count / 3u;
+    float model[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 col = a.model[(size_t)instance * 4 + q];
+      model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
+    }
+    const bool affine = model_is_affine(model, a.geometry_finite);
+    const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
+    if (!fits && lane == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t dst_tri = (size_t)first_index / 3u;
+    const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
+    uint32_t survivors = 0;
+
+    // one loop per path: the choice is per command, not per step
+    auto walk = [&](auto affine_tag) {
+      constexpr bool kAffine = decltype(affine_tag)::value;
+      // software pipeline: the index triple of step k+1 is in flight while step k gathers and tests
+      uint32_t n0 = 0, n1 = 0, n2 = 0;
+      if (lane < n_tris) {
+        const uint32_t* ip = tri_indices + (size_t)lane * 3;
+        n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+      }
+      for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
+        const uint32_t t = t0 + lane;
+        const bool valid = t < n_tris;
+        const uint32_t i0 = n0, i1 = n1, i2 = n2;
+        if (t + 64u < n_tris) {
+          const uint32_t* ip = tri_indices + (size_t)(t + 64u) * 3;
+          n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+        }
+        float v[9];
+        triangle_fetch(a.vertices, (long long)vertex_offset, i0, i1, i2, v);
+        const bool keep = valid && !triangle_test<kAffine>(model, pv, v);
+        const unsigned long long mask = __ballot(keep);
+        if (keep && fits) {
+          uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
+          dst[0] = i0; dst[1] = i1; dst[2] = i2;
+        }
+        survivors += (uint32_t)__popcll(mask);
+      }
+    };
+    if (affine) walk(std::true_type{});
+    else walk(std::false_type{});
+    if (lane == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;  // the command's final indexCount
+  }
+}
+
+// Small frames (the reference's own regime: tens to a few thousand commands) leave a
+// wave-per-command launch mostly idle and make one wave walk a 15 k-triangle mesh alone
+// (measured 0.1 ms for 20 commands). There ONE WORKGROUP of 1024 threads takes a command:
+// 1024 triangles per step, survivors ordered by a ballot per wave + the 16 wave totals in LDS.
+constexpr uint32_t kTriBlock = 1024;
+
+__global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(const TriangleArgs a) {
+  __shared__ uint32_t s_wave[2][kTriBlock / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t count = *a.count;
+  float pv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
+
+  for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+    const uint32_t index_count = a.cmds[c * kCmdWords + 0];
+    const uint32_t first_index = a.cmds[c * kCmdWords + 2];
+    const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
+    const uint32_t instance = a.cmds[c * kCmdWords + 4] - a.first_instance_base;
+    const uint32_t src_tri = a.src_index_offset[c] / 3u;
+    const uint32_t n_tris = index_count / 3u;
+    float model[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 col = a.model[(size_t)instance * 4 + q];
+      model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
+    }
+    const bool affine = model_is_affine(model, a.geometry_finite);
+    const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
+    if (!fits && tid == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t dst_tri = (size_t)first_index / 3u;
+    const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
+    uint32_t survivors = 0, buf = 0;
+    __syncthreads();  // the previous command's last totals have been read
+    for (uint32_t t0 = 0; t0 < n_tris; t0 += kTriBlock, buf ^= 1u) {
+      const uint32_t t = t0 + tid;
+      const bool valid = t < n_tris;
+      const uint32_t* ip = tri_indices + (size_t)(valid ? t : 0u) * 3;
+      const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+      const bool keep = valid && !triangle_culled(affine, model, pv, a.vertices, (long long)vertex_offset, i0, i1, i2);
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) s_wave[buf][wave] = (uint32_t)__popcll(mask);
+      __syncthreads();  // one barrier per step: the totals alternate between two buffers
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kTriBlock / 64; ++w) {
+        const uint32_t v = s_wave[buf][w];
+        if (w < wave) before += v;
+        total += v;
+      }
+      if (keep && fits) {
+        uint32_t* dst = a.out_indices + (dst_tri + survivors + before + lanes_below(mask)) * 3;
+        dst[0] = i0; dst[1] = i1; dst[2] = i2;
+      }
+      survivors += total;
+    }
+    if (tid == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;
+  }
+}
+
+// compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
+// dropped, order kept. One workgroup of 1024 threads walks the (already dense) list.
+struct RecompactArgs {
+  const uint32_t* in_cmds;
+  const uint32_t* in_count;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+};
+
+__global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_running;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t count = *a.in_count;
+  if (tid == 0) s_running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < count; base += 1024u) {
+    const uint32_t k = base + tid;
+    const bool valid = k < count;
+    uint32_t w[kCmdWords];
+#pragma unroll
+    for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? a.in_cmds[(size_t)k * kCmdWords + f] : 0u;
+    const bool keep = valid && w[0] > 0u;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = s_running, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+      if (q < wave) before += s_wave[q];
+      total += s_wave[q];
+    }
+    if (keep) {
+      uint32_t* dst = a.out_cmds + (size_t)(before + lanes_below(mask)) * kCmdWords;
+#pragma unroll
+      for (uint32_t f = 0; f < kCmdWords; ++f) dst[f] = w[f];
+    }
+    __syncthreads();
+    if (tid == 0) s_running += total;
+    __syncthreads();
+  }
+  if (tid == 0) *a.out_count = s_running;
+}
+
+}  // namespace mip

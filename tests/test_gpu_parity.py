@@ -242,6 +242,7 @@ def test_merge_draw_lists_on_device(ra, oracle_mod):
     stride = chunk_stride_bytes(cap)
     dev = torch.device("cuda", 0)
     recv = torch.zeros(len(spans) * stride // 4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     with ra.InstancePipeline(max_instances=cap, max_meshes=64) as p:
         p.set_mesh_table(s["meshes"])
         for k, (lo, hi) in enumerate(spans):
@@ -251,6 +252,7 @@ def test_merge_draw_lists_on_device(ra, oracle_mod):
                          draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4)
         merged = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
         count = torch.zeros(2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         p.merge_draw_lists(recv.data_ptr(), len(spans), stride, merged.data_ptr(), count.data_ptr())
         want = run_oracle(oracle_mod, s, threads=8)
         total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
@@ -284,6 +286,7 @@ def test_config4_ten_million_in_eight_shards(ra, oracle_mod):
         bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
         cmds = torch.zeros((want["draw_count"] + 16, 5), dtype=torch.int32, device=dev)  # exactly enough: nothing may land past the count
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # torch fills on its own stream; the library's streams do not wait for it
         p.run_device(make_frame(s["planes"], s["cam_pos"]), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
                      draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
         count, index_total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
@@ -298,12 +301,14 @@ def test_config4_ten_million_in_eight_shards(ra, oracle_mod):
         cap = 400_000  # v = 0.27: ~337 k commands per shard
         stride = chunk_stride_bytes(cap)
         recv = torch.zeros(world * stride // 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         for r, (lo, hi) in enumerate(spans):
             p.set_instances(s["pos"][lo:hi], s["rot"][lo:hi], s["scale"][lo:hi], s["mesh_id"][lo:hi])
             base = recv.data_ptr() + r * stride
             p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=lo),
                          draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4)
         cmds.zero_()
+        torch.cuda.synchronize()
         p.merge_draw_lists(recv.data_ptr(), world, stride, cmds.data_ptr(), scal.data_ptr())
         count, index_total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
         assert count == want["draw_count"] and index_total == want["draw_index_total"]
@@ -453,6 +458,7 @@ def test_tlas_instance_rows(ra, oracle_mod):
         for with_model in (True, False):
             tlas = torch.zeros((s["n"], 16), dtype=torch.int32, device=dev)
             model = torch.zeros((s["n"], 16), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
             p.run_device(frame, model=model.data_ptr() if with_model else 0, tlas_instances=tlas.data_ptr())
             got = tlas.cpu().numpy().view(np.uint32)
             assert np.array_equal(got[:, 12:], want[:, 12:])                       # index|mask, sbt|flags, BLAS address
@@ -544,11 +550,12 @@ def test_light_draw_lists(ra, oracle_mod):
             p.set_mesh_table(s["meshes"])
             p.set_instances(pos, s["rot"], s["scale"], s["mesh_id"])
             out = torch.full((n_lights * n + 1, 5), -1, dtype=torch.int32, device=dev)
+            out2 = torch.full((n_lights * n + 2, 5), -1, dtype=torch.int32, device=dev)  # 4-byte-aligned destination only
+            torch.cuda.synchronize()  # torch fills on its own stream; the library's stream does not wait for it
             p.light_draw_lists(lights, out.data_ptr(), first_instance_base=3)
             got = out.cpu().numpy()
             assert got[:-1].tobytes() == want.tobytes(), (n, n_lights)
             assert (got[-1] == -1).all()  # nothing past the last list
-            out2 = torch.full((n_lights * n + 2, 5), -1, dtype=torch.int32, device=dev)  # 4-byte-aligned destination only
             p.light_draw_lists(lights, out2.data_ptr() + 20, first_instance_base=3, async_=True)
             p.wait()
             assert out2.cpu().numpy()[1:-1].tobytes() == want.tobytes(), (n, n_lights, "unaligned")

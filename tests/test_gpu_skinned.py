@@ -63,6 +63,7 @@ def _run_gpu(ra, s, sk, poses, first_instance_base=0, first_index_base=0, device
         cmds = torch.zeros((max(n, 1), 5), dtype=torch.int32, device=dev)
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
         frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=first_instance_base, first_index_base=first_index_base)
+        torch.cuda.synchronize()  # torch fills on its own stream; the library's streams do not wait for it
         for _ in range(repeat):
             p.run_skinned(frame, palette=palette.data_ptr(), model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(),
                           draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4,
