@@ -259,6 +259,7 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
     p.set_geometry(vertices, indices)
     p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
     o = DeviceOutputs(torch, n, device)
+    torch.cuda.synchronize()  # torch fills on its own stream; the library does not wait for it
     frame = make_frame(s["planes"], s["cam_pos"], pv=pv)
     p.run_device(frame, **o.kwargs())
     count0, total = (int(x) & 0xFFFFFFFF for x in o.scalars[:2].cpu().tolist())
@@ -502,6 +503,7 @@ def main():
                 p2.set_mesh_table(s2["meshes"])
                 p2.set_instances(s2["pos"], s2["rot"], s2["scale"], s2["mesh_id"])
                 o2 = [DeviceOutputs(torch, s2["n"], device) for _ in range(nf)]
+                torch.cuda.synchronize()  # torch fills on its own stream; the library does not wait for it
                 kw2 = [p2.prepare_outputs(**o.kwargs()) for o in o2]
                 f2r = p2.frame_ref(f2)
                 c2 = [0]
@@ -551,6 +553,7 @@ def main():
             p4.set_mesh_table(s4["meshes"])
             p4.set_instances(s4["pos"], s4["rot"], s4["scale"], s4["mesh_id"])
             o4 = DeviceOutputs(torch, n4, device)
+            torch.cuda.synchronize()  # torch fills on its own stream; the library does not wait for it
             f4 = make_frame(s4["planes"], s4["cam_pos"], first_instance_base=rank * n4)
             ex = DrawListExchange(p4, n4, world, rank, device)
             ex.step(f4, o4)

@@ -29,6 +29,7 @@ def main():
         bitmap = torch.zeros(((n + 31) // 32 + 1,), dtype=torch.int32, device=dev)
         cmds = torch.empty((n, 5), dtype=torch.int32, device=dev)
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         aabb = torch.empty((n, 6), dtype=torch.float32, device=dev)
         frame = make_frame(s["planes"], s["cam_pos"])
         variants = {

@@ -28,6 +28,7 @@ for F in (1, 2, 3, 4):
         bitmap = torch.zeros(((n + 31) // 32 + 1,), dtype=torch.int32, device=dev)
         cmds = torch.empty((n, 5), dtype=torch.int32, device=dev)
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
                   draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
         prepared = p.prepare_outputs(**kw)

@@ -22,6 +22,7 @@ p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
 cap = 360_000
 stride = chunk_stride_bytes(cap)
 recv = torch.zeros(R * stride // 4, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
 for k in range(R):
     base = recv.data_ptr() + k * stride
     p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=k * n), draw_cmds=base + SHARD_HEADER_BYTES,
@@ -29,6 +30,7 @@ for k in range(R):
 count = int(recv[0].item())
 merged = torch.zeros((R * cap, 5), dtype=torch.int32, device=dev)
 oc = torch.zeros(2, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
 for _ in range(5):
     p.merge_draw_lists(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr())
 p.reset_timings()

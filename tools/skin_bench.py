@@ -30,6 +30,7 @@ palette = torch.empty((n, j, 16), dtype=torch.float32, device=dev)
 bitmap = torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=dev)
 cmds = torch.empty((n, 5), dtype=torch.int32, device=dev)
 scal = torch.zeros(8, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
 frame = make_frame(s["planes"], s["cam_pos"])
 kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
           draw_index_total=scal.data_ptr() + 4)

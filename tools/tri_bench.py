@@ -26,6 +26,7 @@ model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
 bitmap = torch.zeros(((n + 31) // 32 + 1,), dtype=torch.int32, device=dev)
 cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
 scal = torch.zeros(8, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
 frame = make_frame(s["planes"], s["cam_pos"], pv=scene.default_pv())
 p.run_device(frame, model=model.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
 count0, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
