@@ -91,7 +91,8 @@ struct MipContext {
   size_t status_bytes = 0;
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
-  uint32_t tri_block_max = 24576;  // instance counts up to this use the workgroup-per-command triangle kernel
+  uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
+  uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   // staging for MIP_OUT_HOST
@@ -383,6 +384,10 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
+    if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_THREADS")) {
+      const uint32_t v = (uint32_t)std::atoi(env);
+      if (v == 256u || v == 512u || v == 1024u) ctx->tri_block_threads = v;
+    }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_GRAPH_ROUND")) ctx->graph_round = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
@@ -628,8 +633,19 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       // The command count lives on the device; the instance count bounds it. Small frames: one
       // 1024-thread workgroup per command; large frames: one wave per command (no barriers).
       if (n <= ctx->tri_block_max) {
-        uint32_t blocks = n < (uint32_t)ctx->cu_count * 2u ? n : (uint32_t)ctx->cu_count * 2u;
-        hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel, dim3(blocks ? blocks : 1u), dim3(mip::kTriBlock), 0, stream, t);
+        // workgroup size: the register budget allows 16 waves per CU, so 1024 / 512 / 256 threads = 1 / 2 / 4
+        // workgroups per CU; smaller workgroups wait less at the per-step barrier, larger ones finish a
+        // lone command sooner
+        // measured (DamagedHelmet table entry): <= 4 k instances 1024 threads (25 vs 37 us at 48 commands),
+        // above that 256 (20 k instances: 0.27 vs 0.35 ms; mixed 64-mesh scene, 20 k: 0.19 ms vs 0.41 ms for
+        // wave-per-command); from ~65 k instances wave-per-command wins (100 k: 1.15 vs 1.21 ms)
+        const uint32_t tb = ctx->tri_block_threads ? ctx->tri_block_threads : (n <= 4096u ? 1024u : 256u);
+        const uint32_t per_cu = 2u * (1024u / tb);
+        uint32_t blocks = n < (uint32_t)ctx->cu_count * per_cu ? n : (uint32_t)ctx->cu_count * per_cu;
+        if (!blocks) blocks = 1u;
+        if (tb == 256u) hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<256>, dim3(blocks), dim3(256), 0, stream, t);
+        else if (tb == 512u) hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<512>, dim3(blocks), dim3(512), 0, stream, t);
+        else hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, t);
       } else {
         uint32_t blocks = (n + 3u) / 4u;
         const uint32_t max_blocks = (uint32_t)ctx->cu_count * 8u;

@@ -195,8 +195,7 @@ __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_
 // wave-per-command launch mostly idle and make one wave walk a 15 k-triangle mesh alone
 // (measured 0.1 ms for 20 commands). There ONE WORKGROUP of 1024 threads takes a command:
 // 1024 triangles per step, survivors ordered by a ballot per wave + the 16 wave totals in LDS.
-constexpr uint32_t kTriBlock = 1024;
-
+template <uint32_t kTriBlock>
 __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(const TriangleArgs a) {
   __shared__ uint32_t s_wave[2][kTriBlock / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

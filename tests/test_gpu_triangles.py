@@ -65,6 +65,28 @@ def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     assert 0 < survivors < int(r["draw_cmds"]["indexCount"].astype(np.int64).sum())  # something was culled, something survived
 
 
+@pytest.mark.parametrize("mode", ["wave", "block256", "block512", "block1024"])
+def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
+    """The library picks wave-per-command or a 256/512/1024-thread workgroup per command by instance count;
+    here each variant is forced (tuning variables, read by mip_create) onto the same mixed scene."""
+    if mode == "wave":
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+    else:
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "100000000")
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_THREADS", mode[5:])
+    s = ra.scene.make_scene(3, n=7000)
+    s["pos"][11, 1] = np.nan  # one command takes the literal (non-affine) path
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    pv = ra.scene.default_pv()
+    r0 = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
+    capacity = r0["draw_index_total"] + 3
+    r, want_cmds, want_out = _oracle(oracle_mod, s, vertices, indices, pv, capacity, first_instance_base=17)
+    got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, frames=2, first_instance_base=17)
+    assert count == len(want_cmds) and total == r["draw_index_total"], mode
+    assert got_cmds.tobytes() == want_cmds.tobytes(), mode
+    assert np.array_equal(got_out, want_out), mode
+
+
 def test_triangle_cull_special_instances_and_bases(ra, oracle_mod):
     s = ra.scene.make_scene(3, n=2000, all_visible=True)
     s["pos"][5, 0] = np.nan          # NaN model matrix: every comparison is false, so every triangle survives
