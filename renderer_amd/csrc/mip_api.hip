@@ -449,7 +449,10 @@ int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint3
   if (!ctx->have_meshes || m != ctx->m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u addresses for %u meshes", m, ctx->m);
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
-  if (!ctx->d_blas) MIP_HIP(ctx, hipMalloc(&ctx->d_blas, (size_t)(ctx->max_meshes ? ctx->max_meshes : 1) * 8));
+  if (!ctx->d_blas) {
+    MIP_HIP(ctx, hipMalloc(&ctx->d_blas, (size_t)(ctx->max_meshes ? ctx->max_meshes : 1) * 8));
+    ctx->graph_generation++;  // recorded launches carry the old (null) table pointer
+  }
   if (m) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_blas, addresses, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
   MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // uploads are stream-ordered copies: finished before any slot launches again
   return MIP_OK;
