@@ -639,10 +639,10 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
         // workgroup size: the register budget allows 16 waves per CU, so 1024 / 512 / 256 threads = 1 / 2 / 4
         // workgroups per CU; smaller workgroups wait less at the per-step barrier, larger ones finish a
         // lone command sooner
-        // measured (DamagedHelmet table entry): <= 4 k instances 1024 threads (25 vs 37 us at 48 commands),
-        // above that 256 (20 k instances: 0.27 vs 0.35 ms; mixed 64-mesh scene, 20 k: 0.19 ms vs 0.41 ms for
-        // wave-per-command); from ~65 k instances wave-per-command wins (100 k: 1.15 vs 1.21 ms)
-        const uint32_t tb = ctx->tri_block_threads ? ctx->tri_block_threads : (n <= 4096u ? 1024u : 256u);
+        // measured (DamagedHelmet table entry, frame time in us at 256 / 512 / 1024 threads): 200 instances
+        // 35 / 28 / 27, 1000: 60 / 49 / 56, 2000: 72 / 66 / 73, 4000: 85 / 88 / 108, 20 k: 266 / 324 / 347;
+        // from ~65 k instances wave-per-command wins (100 k: 1.15 vs 1.21 ms)
+        const uint32_t tb = ctx->tri_block_threads ? ctx->tri_block_threads : (n <= 768u ? 1024u : (n <= 3072u ? 512u : 256u));
         const uint32_t per_cu = 2u * (1024u / tb);
         uint32_t blocks = n < (uint32_t)ctx->cu_count * per_cu ? n : (uint32_t)ctx->cu_count * per_cu;
         if (!blocks) blocks = 1u;
