@@ -191,6 +191,56 @@ __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_
   }
 }
 
+// compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
+// dropped, order kept. One workgroup of kThreads threads walks the (already dense) list.
+template <uint32_t kThreads>
+__device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, uint32_t count, uint32_t* out_cmds, uint32_t* out_count,
+                                                   uint32_t (&s_totals)[kThreads / 64], uint32_t& s_running) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) s_running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < count; base += kThreads) {
+    const uint32_t k = base + tid;
+    const bool valid = k < count;
+    uint32_t w[kCmdWords];
+#pragma unroll
+    for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? in_cmds[(size_t)k * kCmdWords + f] : 0u;
+    const bool keep = valid && w[0] > 0u;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) s_totals[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = s_running, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kThreads / 64; ++q) {
+      if (q < wave) before += s_totals[q];
+      total += s_totals[q];
+    }
+    if (keep) {
+      uint32_t* dst = out_cmds + (size_t)(before + lanes_below(mask)) * kCmdWords;
+#pragma unroll
+      for (uint32_t f = 0; f < kCmdWords; ++f) dst[f] = w[f];
+    }
+    __syncthreads();
+    if (tid == 0) s_running += total;
+    __syncthreads();
+  }
+  if (tid == 0) *out_count = s_running;
+}
+
+struct RecompactArgs {
+  const uint32_t* in_cmds;
+  const uint32_t* in_count;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+};
+
+// Its own launch after the wave-per-command kernel (large frames).
+__global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
+  __shared__ uint32_t s_totals[16];
+  __shared__ uint32_t s_running;
+  recompact_commands<1024>(a.in_cmds, *a.in_count, a.out_cmds, a.out_count, s_totals, s_running);
+}
+
 // Small frames (the reference's own regime: tens to a few thousand commands) leave a
 // wave-per-command launch mostly idle and make one wave walk a 15 k-triangle mesh alone
 // (measured 0.1 ms for 20 commands). There ONE WORKGROUP of 1024 threads takes a command:
@@ -279,50 +329,6 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
     }
     if (tid == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;
   }
-}
-
-// compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
-// dropped, order kept. One workgroup of 1024 threads walks the (already dense) list.
-struct RecompactArgs {
-  const uint32_t* in_cmds;
-  const uint32_t* in_count;
-  uint32_t* out_cmds;
-  uint32_t* out_count;
-};
-
-__global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_running;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t count = *a.in_count;
-  if (tid == 0) s_running = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < count; base += 1024u) {
-    const uint32_t k = base + tid;
-    const bool valid = k < count;
-    uint32_t w[kCmdWords];
-#pragma unroll
-    for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? a.in_cmds[(size_t)k * kCmdWords + f] : 0u;
-    const bool keep = valid && w[0] > 0u;
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t before = s_running, total = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < 16; ++q) {
-      if (q < wave) before += s_wave[q];
-      total += s_wave[q];
-    }
-    if (keep) {
-      uint32_t* dst = a.out_cmds + (size_t)(before + lanes_below(mask)) * kCmdWords;
-#pragma unroll
-      for (uint32_t f = 0; f < kCmdWords; ++f) dst[f] = w[f];
-    }
-    __syncthreads();
-    if (tid == 0) s_running += total;
-    __syncthreads();
-  }
-  if (tid == 0) *a.out_count = s_running;
 }
 
 }  // namespace mip
