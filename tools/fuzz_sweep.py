@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""A longer fuzz sweep than the test suite runs: random scenes with special floating-point values through every
+GPU path (instance frame, light lists, skinned frame, per-triangle stage) against the oracle.
+usage: tools/fuzz_sweep.py [seeds] [first_seed]   — prints one line per 25 seeds, exits non-zero on a mismatch."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402  (checker only)
+import renderer_amd as ra  # noqa: E402
+from fuzz_scenes import SPECIAL, random_scene  # noqa: E402
+from helpers import float_mismatches  # noqa: E402
+from renderer_amd.pipeline import make_frame  # noqa: E402
+
+seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda", 0)
+
+
+def same(a, b):
+    return len(float_mismatches(np.asarray(a).reshape(np.asarray(b).shape), b)) == 0
+
+
+def fail(seed, what):
+    print(f"MISMATCH seed {seed}: {what}", flush=True)
+    sys.exit(1)
+
+
+def random_skeleton(rng, j):
+    parent = np.array([-1] + [int(rng.integers(-1 if k % 5 == 4 else 0, k)) for k in range(1, j)], np.int32)
+    ibm = np.tile(np.eye(4, dtype=np.float32).reshape(16), (j, 1))
+    ibm[:, 12:15] = rng.uniform(-1, 1, (j, 3))
+    ibm[:, [0, 5, 10]] = rng.uniform(0.8, 1.2, (j, 3))
+    lo = rng.uniform(-1, 0, (j, 3)).astype(np.float32)
+    box = np.concatenate([lo, lo + rng.uniform(-0.2, 1.0, (j, 3)).astype(np.float32)], axis=1)  # some boxes are empty
+    return dict(parent=parent, inverse_bind=ibm, joint_box=box)
+
+
+done = 0
+for seed in range(first, first + seeds):
+    rng = np.random.default_rng(50_000 + seed)
+    s = random_scene(rng, oracle, n_max=int(rng.choice([300, 3000, 40_000])), special_rate=float(rng.choice([0.0, 0.01, 0.05])))
+    n = s["n"]
+    fib, fxb = s["first_instance_base"], s["first_index_base"]
+    want = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"],
+                      first_instance_base=fib, first_index_base=fxb, threads=8)
+    with ra.InstancePipeline(max_instances=max(n, 1), max_meshes=64, frames_in_flight=int(rng.integers(1, 4))) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb)
+        if not (np.array_equal(got["visible_bitmap"], want["visible_bitmap"]) and got["draw_count"] == want["draw_count"]
+                and got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes() and got["draw_index_total"] == want["draw_index_total"]
+                and same(got["model"], want["model"]) and same(got["world_aabb"], want["world_aabb"])):
+            fail(seed, f"instance frame n={n}")
+        if n:
+            # light lists
+            lights = rng.normal(0, 30, (int(rng.integers(1, 17)), 3)).astype(np.float32)
+            lights[rng.random(lights.shape) < 0.05] = rng.choice(SPECIAL)
+            out = torch.full((len(lights) * n + 1, 5), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            p.light_draw_lists(lights, out.data_ptr(), first_instance_base=fib)
+            wl = oracle.light_draw_lists(s["pos"], s["mesh_id"], s["meshes"], lights, first_instance_base=fib)
+            if out.cpu().numpy()[:-1].tobytes() != wl.tobytes():
+                fail(seed, f"light lists n={n} lights={len(lights)}")
+            # skinned frame
+            j = int(rng.integers(1, 33))
+            sk = random_skeleton(rng, j)
+            poses = np.empty((n, j, 10), np.float32)
+            poses[:, :, 0:3] = rng.uniform(-0.5, 0.5, (n, j, 3))
+            q = rng.normal(size=(n, j, 4))
+            poses[:, :, 3:7] = q / np.linalg.norm(q, axis=2, keepdims=True)
+            poses[:, :, 7:10] = rng.uniform(0.7, 1.3, (n, j, 3))
+            hit = rng.random(poses.shape) < 0.002
+            poses[hit] = rng.choice(SPECIAL, int(hit.sum()))
+            ws = oracle.run_skinned(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], sk, poses, s["planes"], s["cam_pos"],
+                                    first_instance_base=fib, first_index_base=fxb)
+            p.set_skeleton(sk["parent"], sk["inverse_bind"], sk["joint_box"])
+            p.set_poses(poses)
+            model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+            palette = torch.zeros((n, j, 16), dtype=torch.float32, device=dev)
+            aabb = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+            bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)
+            cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            p.run_skinned(make_frame(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb), palette=palette.data_ptr(),
+                          model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                          draw_index_total=scal.data_ptr() + 4, world_aabb=aabb.data_ptr(), async_=False)
+            count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+            if not (count == ws["draw_count"] and total == ws["draw_index_total"]
+                    and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
+                    and np.array_equal(bitmap.cpu().numpy().view(np.uint32), ws["visible_bitmap"])
+                    and same(palette.cpu().numpy(), ws["palette"]) and same(aabb.cpu().numpy(), ws["world_aabb"])
+                    and same(model.cpu().numpy(), ws["model"])):
+                fail(seed, f"skinned frame n={n} joints={j}")
+    # per-triangle stage on a generated scene with real geometry (every third seed: it is the slow one)
+    if seed % 3 == 0:
+        cfg = int(rng.choice([2, 3]))
+        nt = int(rng.choice([40, 900, 5000, 70_000 if seed % 12 == 0 else 2000]))
+        t = ra.scene.make_scene(cfg, n=nt, all_visible=bool(rng.random() < 0.5))
+        hit = rng.random(nt) < 0.01
+        t["scale"][hit] = rng.choice(SPECIAL, int(hit.sum()))
+        vertices, indices = ra.scene.make_geometry(t["meshes"])
+        pv = oracle.camera_pv(cam_pos=tuple(float(x) for x in rng.normal(0, 3, 3)), aspect=float(rng.uniform(0.7, 2.5)),
+                              fovy_degrees=float(rng.uniform(30, 110)))
+        r = oracle.run(t["pos"], t["rot"], t["scale"], t["mesh_id"], t["meshes"], t["planes"], t["cam_pos"], threads=8)
+        cap = r["draw_index_total"] + 3
+        wc, wo, _ = oracle.cull_all_triangles(r, t["pos"], t["mesh_id"], t["meshes"], t["cam_pos"], pv, vertices, indices, out_capacity=cap)
+        with ra.InstancePipeline(max_instances=nt, max_meshes=64) as p:
+            p.set_mesh_table(t["meshes"])
+            p.set_geometry(vertices, indices)
+            p.set_instances(t["pos"], t["rot"], t["scale"], t["mesh_id"])
+            model = torch.zeros((nt, 16), dtype=torch.float32, device=dev)
+            cmds = torch.zeros((nt, 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            out = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            p.run_device(make_frame(t["planes"], t["cam_pos"], pv=pv), model=model.data_ptr(), draw_cmds=cmds.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, culled_index_buffer=out.data_ptr(),
+                         culled_index_capacity=cap)
+            count = int(scal[0].item())
+            if not (count == len(wc) and cmds[:count].cpu().numpy().tobytes() == wc.tobytes()
+                    and np.array_equal(out.cpu().numpy().view(np.uint32), wo)):
+                fail(seed, f"triangle stage cfg={cfg} n={nt}")
+    done += 1
+    if done % 25 == 0:
+        print(f"{done} seeds ok (last: n={n})", flush=True)
+print(f"FUZZ_SWEEP_OK {done} seeds from {first}", flush=True)
