@@ -47,6 +47,10 @@ extern "C" {
 
 /* ---- MipConfig.flags ---- */
 #define MIP_CFG_TIMING 0x1u /* bracket every kernel with hipEvents (mip_get_timings) */
+#define MIP_CFG_ORDERED_TILES 0x2u /* hand tile numbers out from a counter instead of taking the workgroup index: the
+                                     * cross-tile prefix then cannot stall whatever order the hardware starts workgroups
+                                     * in (about one atomic round trip slower per workgroup). A context switches itself
+                                     * to this mode after a MIP_ERR_TIMEOUT. */
 
 /* ---- MipOutputs.flags ---- */
 #define MIP_OUT_HOST 0x0u   /* output pointers are host memory (copied back, synchronous) */

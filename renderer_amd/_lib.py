@@ -18,6 +18,7 @@ ERR_NAMES = {
     -7: "MIP_ERR_TIMEOUT",
 }
 MIP_CFG_TIMING = 0x1
+MIP_CFG_ORDERED_TILES = 0x2
 MIP_OUT_HOST = 0x0
 MIP_OUT_DEVICE = 0x1
 MIP_OUT_ASYNC = 0x2

@@ -81,7 +81,8 @@ struct KernelArgs {
   float* world_aabb;            // n*6 or null
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
-  const float* box_override;    // n*6 or null: per-instance mesh-space box (min xyz, max xyz) that replaces the mesh table's (skinned instances)
+  uint32_t* tile_ticket;        // ordered-tiles variant only: next tile number, 0 between launches
+  const float* box_override;    // n*8 or null: per-instance mesh-space box {min xyz, -, max xyz, -} that replaces the mesh table's (skinned instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
@@ -447,6 +448,15 @@ __device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t til
 // the kernel
 // ---------------------------------------------------------------------------------------
 
+// kTicketedTiles: a workgroup's tile number comes from a ticket counter instead of blockIdx.x. Tiles
+// wait only for lower-numbered tiles, and a ticket is only ever held by a workgroup that is already
+// running, so the waits cannot deadlock whatever order the hardware starts workgroups in — at the
+// price of one atomic round trip at the head of every workgroup. The library switches to this
+// variant after a MIP_ERR_TIMEOUT (or with MIP_CFG_ORDERED_TILES); the default keeps blockIdx.x.
+// kBoxOverride: every instance brings its own mesh-space box (KernelArgs.box_override; the skinned
+// extension). A separate instantiation because the extra live values make the cold literal path spill
+// 16 bytes per lane, which the ordinary frame's kernel should not carry.
+template <bool kTicketedTiles, bool kBoxOverride>
 __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pipeline_kernel(const KernelArgs a) {
   __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
   __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
@@ -458,7 +468,18 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t tile = blockIdx.x;
+  uint32_t tile = blockIdx.x;
+  if constexpr (kTicketedTiles) {
+    __shared__ uint32_t s_tile;
+    if (tid == 0) {
+      s_tile = atomicAdd(a.tile_ticket, 1u);
+      // the holder of the last ticket knows every other workgroup already has its own: it re-arms
+      // the counter for the next launch on this frame slot
+      if (s_tile == a.n_tiles - 1u) __hip_atomic_store(a.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    tile = s_tile;
+  }
   const uint32_t tile_first = tile * kTile;
   const uint32_t i = tile_first + tid;
   const bool active = i < a.n;
@@ -486,13 +507,13 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
     for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
-  if (a.box_override) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
-    const float2* b2 = reinterpret_cast<const float2*>(a.box_override + (size_t)il * 6);
-    const float2 b01 = b2[0], b23 = b2[1], b45 = b2[2];
-    mb.min_x = b01.x; mb.min_y = b01.y; mb.min_z = b23.x;
-    mb.max_x = b23.y; mb.max_y = b45.x; mb.max_z = b45.y;
+  if constexpr (kBoxOverride) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
+    const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;  // {min xyz, -}, {max xyz, -}
+    const float4 lo = b4[0], hi = b4[1];
+    mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
+    mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
     // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
-    mag += fabsf(b01.x) + fabsf(b01.y) + fabsf(b23.x) + fabsf(b23.y) + fabsf(b45.x) + fabsf(b45.y);
+    mag += fabsf(lo.x) + fabsf(lo.y) + fabsf(lo.z) + fabsf(hi.x) + fabsf(hi.y) + fabsf(hi.z);
   }
   const bool all_finite = mag < 3.0e38f;
   Instance inst;

@@ -29,13 +29,14 @@ struct MipContext {
   uint32_t max_instances = 0, max_meshes = 0, cfg_flags = 0;
   uint32_t n = 0, m = 0;
   bool have_instances = false, have_meshes = false;
+  bool ordered_tiles = false;  // MIP_CFG_ORDERED_TILES, or set by the first MIP_ERR_TIMEOUT
   // One slot per frame in flight: its own stream and its own cross-tile prefix state, so that
   // consecutive frames may overlap on the device (MipConfig.frames_in_flight).
   struct FrameSlot {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     unsigned long long* d_status = nullptr;  // level-0 granules, accumulators, group starts
-    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket
+    uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket, [5] tile ticket (ordered tiles)
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t epoch = 0;         // highest tag handed out on this state
@@ -85,7 +86,7 @@ struct MipContext {
   float* d_poses_owned = nullptr;
   const float* d_poses = nullptr;  // owned copy or a borrowed device pointer
   uint32_t poses_n = 0;
-  float* d_skin_box = nullptr;  // per instance posed mesh-space box (min xyz, max xyz)
+  float* d_skin_box = nullptr;  // per instance posed mesh-space box {min xyz, -, max xyz, -}
   int cu_count = 0;
   // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
@@ -161,9 +162,15 @@ int32_t check_device_error(MipContext* ctx) {
   const uint32_t e = *(volatile uint32_t*)ctx->h_error;
   if (e) {
     *(volatile uint32_t*)ctx->h_error = 0;
-    if (e & mip::kErrTimeout)
+    if (e & mip::kErrTimeout) {
+      // the frame's prefix state is half-written: clear it before the next launch, and from now on
+      // number the tiles from a counter, which cannot stall on the order workgroups start in
+      for (auto& sl : ctx->slots) sl.status_dirty = true;
+      ctx->ordered_tiles = true;
+      ctx->graph_generation++;
       return fail(ctx, MIP_ERR_TIMEOUT,
-                  "prefix wait expired (an earlier tile never published); outputs invalid");
+                  "prefix wait expired (an earlier tile never published); outputs invalid; the context now uses ordered tiles");
+    }
     if (e & mip::kErrIndexOverflow)
       return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
     return fail(ctx, MIP_ERR_CAPACITY,
@@ -218,6 +225,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
     a.tlas_instances = (uint4*)out->tlas_instances;
     a.blas_address = ctx->d_blas;
   }
+  a.tile_ticket = sl.d_scalars + 5;
   a.status0 = sl.d_status;
   a.acc1 = sl.d_status + ctx->acc1_offset_words;
   a.start1 = sl.d_status + ctx->start1_offset_words;
@@ -341,6 +349,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
   ctx->max_instances = cfg->max_instances;
   ctx->max_meshes = cfg->max_meshes;
   ctx->cfg_flags = cfg->flags;
+  ctx->ordered_tiles = (cfg->flags & MIP_CFG_ORDERED_TILES) != 0;
 
   int32_t rc = [&]() -> int32_t {
     MIP_HIP(ctx, hipSetDevice(ctx->device));
@@ -389,6 +398,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
       if (v == 256u || v == 512u || v == 1024u) ctx->tri_block_threads = v;
     }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_ORDERED_TILES")) ctx->ordered_tiles = std::atoi(env) != 0;
     if (const char* env = std::getenv("MIP_TUNE_GRAPH_ROUND")) ctx->graph_round = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
       for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
@@ -615,7 +625,16 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(mip::kSkinBlock), 0, stream, k);
       MIP_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(mip::mip_instance_pipeline_kernel, dim3(a.n_tiles), dim3(mip::kTile), ctx->lds_pad, stream, a);
+    {
+      const dim3 grid(a.n_tiles), block(mip::kTile);
+      if (skinned) {
+        if (ctx->ordered_tiles) hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<true, true>), grid, block, ctx->lds_pad, stream, a);
+        else hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<false, true>), grid, block, ctx->lds_pad, stream, a);
+      } else {
+        if (ctx->ordered_tiles) hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<true, false>), grid, block, ctx->lds_pad, stream, a);
+        else hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<false, false>), grid, block, ctx->lds_pad, stream, a);
+      }
+    }
     MIP_HIP(ctx, hipGetLastError());
     if (triangles) {
       mip::TriangleArgs t{};
@@ -768,7 +787,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const Mi
         a.epoch = base + 1 + j;
         void* params[1] = {&a};
         hipKernelNodeParams kp{};
-        kp.func = (void*)mip::mip_instance_pipeline_kernel;
+        kp.func = ctx->ordered_tiles ? (void*)mip::mip_instance_pipeline_kernel<true, false> : (void*)mip::mip_instance_pipeline_kernel<false, false>;
         kp.gridDim = dim3(a.n_tiles);
         kp.blockDim = dim3(mip::kTile);
         kp.sharedMemBytes = ctx->lds_pad;
@@ -920,7 +939,7 @@ int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs
   if (!ctx->n_joints || ctx->poses_n != ctx->n || (ctx->n && !ctx->d_poses))
     return fail(ctx, MIP_ERR_NOT_READY, "skeleton or poses not set for the resident instances");
   if (int32_t rc = bind_device(ctx)) return rc;
-  if (!ctx->d_skin_box) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_box, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * 24));
+  if (!ctx->d_skin_box) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_box, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * 32));
   return run_frame(ctx, frame, out, true, palette);
 }
 

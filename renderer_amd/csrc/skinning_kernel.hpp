@@ -52,7 +52,7 @@ struct SkinArgs {
   const float* poses;          // n * J * 10, 8-byte aligned
   const JointEntry* joints;    // J
   float4* palette;             // n * J * 4 (mat4 column-major) or null
-  float* local_box;            // n*6: min xyz, max xyz of the posed mesh (the fold's raw result)
+  float* local_box;            // n*8: {min xyz, -, max xyz, -} of the posed mesh (the fold's raw result; slots 3 and 7 unused)
   uint32_t n;
   uint32_t n_joints;
   uint32_t max_depth;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
       const float x = src[k * 6u];
       v = is_min ? fminf(v, x) : fmaxf(v, x);
     }
-    a.local_box[(size_t)block_first * 6u + e] = v;
+    a.local_box[(size_t)(block_first + inst_l) * 8u + comp + (comp >= 3u ? 1u : 0u)] = v;
   }
 }
 

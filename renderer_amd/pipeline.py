@@ -46,7 +46,8 @@ def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0, pv=No
 class InstancePipeline:
     """One context on one GPU (one per rank)."""
 
-    def __init__(self, max_instances, max_meshes, device=0, timing=False, stream=None, frames_in_flight=1):
+    def __init__(self, max_instances, max_meshes, device=0, timing=False, stream=None, frames_in_flight=1,
+                 ordered_tiles=False):
         self._lib = _lib.load_library()
         self._ctx = C.c_void_p()
         cfg = MipConfig()
@@ -54,7 +55,7 @@ class InstancePipeline:
         cfg.device_ordinal = int(device)
         cfg.max_instances = int(max_instances)
         cfg.max_meshes = int(max_meshes)
-        cfg.flags = _lib.MIP_CFG_TIMING if timing else 0
+        cfg.flags = (_lib.MIP_CFG_TIMING if timing else 0) | (_lib.MIP_CFG_ORDERED_TILES if ordered_tiles else 0)
         cfg.frames_in_flight = int(frames_in_flight)
         cfg.stream = stream
         rc = self._lib.mip_create(C.byref(cfg), C.byref(self._ctx))

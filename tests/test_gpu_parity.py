@@ -359,6 +359,59 @@ def test_three_million_instances_multi_window_prefix(ra, oracle_mod):
     assert_parity(got, want, "3M")
 
 
+def test_ordered_tiles_variant(ra, oracle_mod):
+    """MIP_CFG_ORDERED_TILES: tile numbers come from a counter (no assumption about the order workgroups
+    start in). Same results, for the plain frame, frames in flight, recorded launch graphs and a skinned
+    frame; the counter re-arms itself between launches."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    dev = torch.device("cuda", 0)
+    for n in (1, 255, 70_000, 1_000_000):
+        s = ra.scene.make_scene(3, n=n)
+        want = run_oracle(oracle_mod, s, threads=8)
+        with ra.InstancePipeline(max_instances=n, max_meshes=64, ordered_tiles=True) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            for rep in range(3):
+                assert_parity(p.run_host(s["planes"], s["cam_pos"]), want, f"ordered n={n} rep={rep}")
+    s = ra.scene.make_scene(3, n=120_000)
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2, ordered_tiles=True) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in range(2):
+            cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                                                        draw_index_total=scal.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        p.run_many(make_frame(s["planes"], s["cam_pos"]), [x[2] for x in sets], 150)  # graphs + single launches
+        p.wait()
+        assert p.timings()["graph_frames"] == 128
+        for cmds, scal, _ in sets:
+            count = int(scal[0].item())
+            assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+    sk = ra.scene.make_skinned_scene(5000)
+    ws = oracle_mod.run_skinned(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"], sk["meshes"], sk["skeleton"], sk["poses"],
+                                sk["planes"], sk["cam_pos"])
+    with ra.InstancePipeline(max_instances=5000, max_meshes=1, ordered_tiles=True) as p:
+        p.set_mesh_table(sk["meshes"])
+        p.set_instances(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"])
+        p.set_skeleton(sk["skeleton"]["parent"], sk["skeleton"]["inverse_bind"], sk["skeleton"]["joint_box"])
+        p.set_poses(sk["poses"])
+        cmds = torch.zeros((5000, 5), dtype=torch.int32, device=dev)
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            p.run_skinned(make_frame(sk["planes"], sk["cam_pos"]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                          draw_index_total=scal.data_ptr() + 4)
+        count = int(scal[0].item())
+        assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
+
+
 def test_bounded_wait_ends_a_stuck_launch_with_an_error():
     """Fault injection (diagnostic build): tile 5 never publishes its aggregate. Every later tile
     depends on it; the bounded in-kernel wait must expire (0.5 s), the launch must finish, and the
@@ -386,8 +439,12 @@ try:
 except renderer_amd.MipError as e:
     print("CODE", e.code, "%.2f" % (time.time() - t0))
 del os.environ["MIP_DEBUG_SKIP_PUBLISH_TILE"]
-r = p.run_host(s["planes"], s["cam_pos"])   # the same context recovers on the next frame
+r = p.run_host(s["planes"], s["cam_pos"])   # the same context recovers on the next frame (now with ordered tiles)
 print("RECOVERED", r["draw_count"])
+q = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]))
+q.set_mesh_table(s["meshes"]); q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+r2 = q.run_host(s["planes"], s["cam_pos"])
+print("SAME", int(r["draw_cmds"].tobytes() == r2["draw_cmds"].tobytes() and (r["visible_bitmap"] == r2["visible_bitmap"]).all()))
 '''
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
@@ -396,6 +453,7 @@ print("RECOVERED", r["draw_count"])
     assert code_line and code_line[0].split()[1] == "-7", out.stdout  # MIP_ERR_TIMEOUT
     assert float(code_line[0].split()[2]) < 10.0
     assert any(l.startswith("RECOVERED") and int(l.split()[1]) > 0 for l in lines), out.stdout
+    assert "SAME 1" in lines, out.stdout
 
 
 def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):
