@@ -39,6 +39,7 @@ struct MipContext {
     uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket, [5] tile ticket (ordered tiles)
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
+    uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
     uint32_t epoch = 0;         // highest tag handed out on this state
     uint32_t last_tag = 0;      // tag of the last launch (what the level-0 words hold now)
     uint32_t zero_buf = 2;      // which accumulator buffer is all-zero now: 0, 1, or 2 = both
@@ -310,6 +311,7 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_scalars);
     (void)hipFree(sl.d_tmp_cmds);
     (void)hipFree(sl.d_tmp_src);
+    (void)hipFree(sl.d_tmp_blocks);
   }
   (void)hipFree(ctx->s_model);
   (void)hipFree(ctx->s_bitmap);
@@ -582,6 +584,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
     if (!sl.d_tmp_cmds) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_cmds, cap * 20));
     if (!sl.d_tmp_src) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_src, cap * 4));
+    if (!sl.d_tmp_blocks) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_blocks, (cap / 1024 + 1) * 4));
     a.cmds = sl.d_tmp_cmds;
     a.draw_count = sl.d_scalars + 2;
     a.src_index_offset = sl.d_tmp_src;
@@ -677,12 +680,25 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       MIP_HIP(ctx, hipGetLastError());
       // (re-compacting inside the workgroup kernels, by the last workgroup to finish, was measured: the
       // agent-scope fences it needs cost more than the launch they save — 1 k instances 65 vs 49 us)
-      mip::RecompactArgs r{};
-      r.in_cmds = sl.d_tmp_cmds;
-      r.in_count = sl.d_scalars + 2;
-      r.out_cmds = (uint32_t*)out->draw_cmds;
-      r.out_count = out->draw_count;
-      hipLaunchKernelGGL(mip::mip_recompact_kernel, dim3(1), dim3(1024), 0, stream, r);
+      if (n <= ctx->tri_block_max) {
+        mip::RecompactArgs r{};
+        r.in_cmds = sl.d_tmp_cmds;
+        r.in_count = sl.d_scalars + 2;
+        r.out_cmds = (uint32_t*)out->draw_cmds;
+        r.out_count = out->draw_count;
+        hipLaunchKernelGGL(mip::mip_recompact_kernel, dim3(1), dim3(1024), 0, stream, r);
+      } else {  // many commands: counts per 1024, one block scans them, scatter
+        mip::RecompactWideArgs r{};
+        r.in_cmds = sl.d_tmp_cmds;
+        r.in_count = sl.d_scalars + 2;
+        r.out_cmds = (uint32_t*)out->draw_cmds;
+        r.out_count = out->draw_count;
+        r.block_base = sl.d_tmp_blocks;
+        r.n_blocks = (n + 1023u) / 1024u;
+        hipLaunchKernelGGL(mip::mip_recompact_count_kernel, dim3(r.n_blocks), dim3(1024), 0, stream, r);
+        hipLaunchKernelGGL(mip::mip_recompact_scan_kernel, dim3(1), dim3(1024), 0, stream, r);
+        hipLaunchKernelGGL(mip::mip_recompact_scatter_kernel, dim3(r.n_blocks), dim3(1024), 0, stream, r);
+      }
       MIP_HIP(ctx, hipGetLastError());
     }
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, stream));
