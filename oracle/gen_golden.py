@@ -71,9 +71,40 @@ def dump(name, s, **extra):
     print(f"{name}: n={s['n']} visible={int((1 - r['coarse_culled']).sum())} cmds={r['draw_count']}")
 
 
+def dump_skinned(name, s):
+    """Extension fixtures (tests/golden/ext/): the skinned frame, inputs + oracle outputs."""
+    sk = s["skeleton"]
+    r = oracle.run_skinned(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], sk, s["poses"], s["planes"], s["cam_pos"])
+    np.savez_compressed(
+        os.path.join(OUT, "ext", name + ".npz"),
+        pos=s["pos"], rot=s["rot"], scale=s["scale"], mesh_id=s["mesh_id"], meshes=s["meshes"], planes=s["planes"], cam_pos=s["cam_pos"],
+        parent=sk["parent"], inverse_bind=sk["inverse_bind"], joint_box=sk["joint_box"], poses=s["poses"],
+        palette=r["palette"], local_box=r["local_box"], model=r["model"], world_aabb=r["world_aabb"],
+        visible_bitmap=r["visible_bitmap"], draw_cmds=r["draw_cmds"], draw_count=np.uint32(r["draw_count"]),
+        draw_index_total=np.uint32(r["draw_index_total"]),
+    )
+    print(f"ext/{name}: n={s['n']} cmds={r['draw_count']}")
+
+
+def dump_lights(name, s, lights, first_instance_base):
+    """Extension fixtures: the shadow pass's per-light draw lists (row f-4)."""
+    lists = oracle.light_draw_lists(s["pos"], s["mesh_id"], s["meshes"], lights, first_instance_base=first_instance_base)
+    np.savez_compressed(os.path.join(OUT, "ext", name + ".npz"), pos=s["pos"], rot=s["rot"], scale=s["scale"], mesh_id=s["mesh_id"],
+                        meshes=s["meshes"], lights=lights, first_instance_base=np.uint32(first_instance_base), lists=lists)
+    print(f"ext/{name}: n={s['n']} lights={len(lights)}")
+
+
 def main():
-    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(os.path.join(OUT, "ext"), exist_ok=True)
     oracle.build()
+    sk_scene = scene.make_skinned_scene(301)
+    sk_scene["poses"][7, 3, 0] = np.nan      # a NaN joint translation
+    sk_scene["poses"][9, :, 7:10] = 0.0      # zero joint scales
+    sk_scene["pos"][11] = np.nan             # NaN instance position
+    dump_skinned("skinned_301", sk_scene)
+    lit = scene.make_scene(3, n=1001)
+    lit["pos"][5] = np.nan
+    dump_lights("lights_1001", lit, np.array([[30, 20, -40.1], [0.1, 17, 0.1], [0, 0, 0], lit["pos"][17]], np.float32), 4)
     dump("box_1024", scene.make_scene(1))  # BASELINE config 1, full outputs
     for n in (1, 63, 64, 65, 257):
         dump(f"mixed_{n}", scene.make_scene(3, n=n, all_visible=(n < 100)))

@@ -95,6 +95,33 @@ def test_rigged_figure_scene(ra, oracle_mod, n):
         assert 0 < want["draw_count"] < n  # the frustum does cut the scene
 
 
+def test_committed_extension_fixtures(ra):
+    """tests/golden/ext/ reproduces on the GPU without the oracle: the skinned frame and the per-light lists."""
+    import os
+
+    import torch
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "ext", "skinned_301.npz"))
+    s = dict(n=len(g["scale"]), pos=g["pos"], rot=g["rot"], scale=g["scale"], mesh_id=g["mesh_id"], meshes=g["meshes"],
+             planes=g["planes"], cam_pos=g["cam_pos"])
+    sk = dict(parent=g["parent"], inverse_bind=g["inverse_bind"], joint_box=g["joint_box"])
+    got = _run_gpu(ra, s, sk, g["poses"])
+    want = {k: g[k] for k in ("palette", "world_aabb", "model", "visible_bitmap", "draw_cmds")}
+    want["draw_count"], want["draw_index_total"] = int(g["draw_count"]), int(g["draw_index_total"])
+    _check(got, want, "fixture skinned_301")
+    g = np.load(os.path.join(here, "golden", "ext", "lights_1001.npz"))
+    n, lights = len(g["scale"]), g["lights"]
+    dev = torch.device("cuda", 0)
+    with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+        p.set_mesh_table(g["meshes"])
+        p.set_instances(g["pos"], g["rot"], g["scale"], g["mesh_id"])
+        out = torch.zeros((len(lights) * n, 5), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        p.light_draw_lists(lights, out.data_ptr(), first_instance_base=int(g["first_instance_base"]))
+        assert out.cpu().numpy().tobytes() == g["lists"].tobytes()
+
+
 @pytest.mark.parametrize("j", [1, 2, 7, 16, 21, 32])
 def test_other_joint_counts_and_hierarchies(ra, oracle_mod, j):
     rng = np.random.default_rng(100 + j)

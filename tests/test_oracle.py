@@ -38,6 +38,20 @@ def test_oracle_reproduces_golden(oracle_mod, path):
         assert same_floats(r["model"], g["model"]) and same_floats(r["world_aabb"], g["world_aabb"])
 
 
+def test_extension_fixtures_reproduce(oracle_mod):
+    """tests/golden/ext/: the skinned frame (BASELINE config 5 extension) and the per-light draw lists."""
+    g = np.load(os.path.join(HERE, "golden", "ext", "skinned_301.npz"))
+    sk = dict(parent=g["parent"], inverse_bind=g["inverse_bind"], joint_box=g["joint_box"])
+    r = oracle_mod.run_skinned(g["pos"], g["rot"], g["scale"], g["mesh_id"], g["meshes"], sk, g["poses"], g["planes"], g["cam_pos"])
+    for key in ("palette", "local_box", "model", "world_aabb"):
+        assert same_floats(r[key].reshape(g[key].shape), g[key]), key
+    assert np.array_equal(r["visible_bitmap"], g["visible_bitmap"]) and r["draw_count"] == int(g["draw_count"])
+    assert r["draw_cmds"].tobytes() == g["draw_cmds"].tobytes() and r["draw_index_total"] == int(g["draw_index_total"])
+    g = np.load(os.path.join(HERE, "golden", "ext", "lights_1001.npz"))
+    lists = oracle_mod.light_draw_lists(g["pos"], g["mesh_id"], g["meshes"], g["lights"], first_instance_base=int(g["first_instance_base"]))
+    assert lists.tobytes() == g["lists"].tobytes()
+
+
 def test_golden_set_is_present():
     names = {os.path.basename(p) for p in GOLDEN}
     assert {"box_1024.npz", "special_513.npz", "mixed_4097_bases.npz"} <= names
