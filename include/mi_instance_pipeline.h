@@ -271,9 +271,11 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
                          const float* joint_box, uint32_t n_joints);
 
 /* The animated pose of every instance: n x n_joints x MIP_POSE_FLOATS floats, instance-major.
- * n must equal the resident instance count. device == 0: host pointer, copied. device != 0: a
- * DEVICE pointer that is borrowed, not copied — an animation system rewrites it between frames
- * and keeps it alive while frames that read it are in flight. */
+ * n must equal the resident instance count. device == 0: host pointer, copied (waits for the frames in
+ * flight). device != 0: a DEVICE pointer (8-byte aligned) that is borrowed, not copied; the call does not
+ * wait for anything — frames already queued keep the pointer they were launched with, so an animation
+ * system can alternate two buffers with frames_in_flight = 2. It keeps each buffer alive and unmodified
+ * while a frame that reads it is in flight. */
 int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_t device);
 
 /* One frame of skinned instances. Per instance and joint

@@ -40,6 +40,7 @@ struct MipContext {
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
+    float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
     uint32_t epoch = 0;         // highest tag handed out on this state
     uint32_t last_tag = 0;      // tag of the last launch (what the level-0 words hold now)
     uint32_t zero_buf = 2;      // which accumulator buffer is all-zero now: 0, 1, or 2 = both
@@ -87,7 +88,6 @@ struct MipContext {
   float* d_poses_owned = nullptr;
   const float* d_poses = nullptr;  // owned copy or a borrowed device pointer
   uint32_t poses_n = 0;
-  float* d_skin_box = nullptr;  // per instance posed mesh-space box {min xyz, -, max xyz, -}
   int cu_count = 0;
   // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
@@ -305,13 +305,13 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_indices);
   (void)hipFree(ctx->d_joints);
   (void)hipFree(ctx->d_poses_owned);
-  (void)hipFree(ctx->d_skin_box);
   for (auto& sl : ctx->slots) {
     (void)hipFree(sl.d_status);
     (void)hipFree(sl.d_scalars);
     (void)hipFree(sl.d_tmp_cmds);
     (void)hipFree(sl.d_tmp_src);
     (void)hipFree(sl.d_tmp_blocks);
+    (void)hipFree(sl.d_skin_box);
   }
   (void)hipFree(ctx->s_model);
   (void)hipFree(ctx->s_bitmap);
@@ -591,7 +591,8 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
   }
   if (skinned) {
     // the posed mesh-space box replaces the mesh table's; computed first, on the same stream
-    a.box_override = ctx->d_skin_box;
+    if (!sl.d_skin_box) MIP_HIP(ctx, hipMalloc(&sl.d_skin_box, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * 32));
+    a.box_override = sl.d_skin_box;  // per frame slot: frames in flight may carry different poses
   }
 
   // Cross-tile prefix state (see instance_kernel.hpp): a fresh tag per launch marks
@@ -617,7 +618,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       k.poses = ctx->d_poses;
       k.joints = ctx->d_joints;
       k.palette = (float4*)palette;
-      k.local_box = ctx->d_skin_box;
+      k.local_box = sl.d_skin_box;
       k.n = n;
       k.n_joints = ctx->n_joints;
       k.max_depth = ctx->max_joint_depth;
@@ -931,16 +932,19 @@ int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_
   if (!ctx->n_joints) return fail(ctx, MIP_ERR_NOT_READY, "set the skeleton before the poses");
   if (!ctx->have_instances || n != ctx->n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u poses for %u instances", n, ctx->n);
   if (!joint_trs && n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "joint_trs is NULL");
-  if (int32_t rc = bind_device(ctx)) return rc;
-  if (int32_t rc = sync_all(ctx)) return rc;
   if (device) {
+    // borrowed: nothing is copied and nothing in flight is touched — frames already queued keep the
+    // pointer they were launched with, so an animation system can alternate two buffers
     ctx->d_poses = (const float*)joint_trs;
   } else {
+    if (int32_t rc = bind_device(ctx)) return rc;
+    if (int32_t rc = sync_all(ctx)) return rc;
     if (!ctx->d_poses_owned)
       MIP_HIP(ctx, hipMalloc(&ctx->d_poses_owned, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * MIP_MAX_JOINTS * MIP_POSE_FLOATS * 4));
-    if (n)
+    if (n) {
       MIP_HIP(ctx, hipMemcpyAsync(ctx->d_poses_owned, joint_trs, (size_t)n * ctx->n_joints * MIP_POSE_FLOATS * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (n) MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->d_poses = ctx->d_poses_owned;
   }
   ctx->poses_n = n;
@@ -955,7 +959,6 @@ int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs
   if (!ctx->n_joints || ctx->poses_n != ctx->n || (ctx->n && !ctx->d_poses))
     return fail(ctx, MIP_ERR_NOT_READY, "skeleton or poses not set for the resident instances");
   if (int32_t rc = bind_device(ctx)) return rc;
-  if (!ctx->d_skin_box) MIP_HIP(ctx, hipMalloc(&ctx->d_skin_box, (size_t)(ctx->max_instances ? ctx->max_instances : 1) * 32));
   return run_frame(ctx, frame, out, true, palette);
 }
 

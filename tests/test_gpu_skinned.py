@@ -175,6 +175,45 @@ def test_non_finite_and_degenerate_inputs(ra, oracle_mod):
     _check(got, want, "all boxes empty")
 
 
+def test_two_pose_buffers_alternate_with_frames_in_flight(ra, oracle_mod):
+    """An animation system double-buffers its poses: frame k reads buffer A while frame k+1, queued behind it on
+    the other frame slot, reads buffer B. Each output set must carry its own pose's result."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_skinned_scene(60_000)
+    sk = s["skeleton"]
+    poses_a = s["poses"]
+    poses_b = ra.scene.make_poses(s["n"], sk, 0xB0B, max_angle_deg=90.0)
+    wants = [oracle_mod.run_skinned(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], sk, p, s["planes"], s["cam_pos"],
+                                    want=("draw_cmds", "palette")) for p in (poses_a, poses_b)]
+    assert wants[0]["draw_cmds"].tobytes() != wants[1]["draw_cmds"].tobytes()
+    dev = torch.device("cuda", 0)
+    n, j = s["n"], len(sk["parent"])
+    with ra.InstancePipeline(max_instances=n, max_meshes=1, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        p.set_skeleton(sk["parent"], sk["inverse_bind"], sk["joint_box"])
+        bufs = [torch.from_numpy(x).to(dev) for x in (poses_a, poses_b)]
+        outs = []
+        for _ in range(2):
+            outs.append(dict(cmds=torch.zeros((n, 5), dtype=torch.int32, device=dev), scal=torch.zeros(8, dtype=torch.int32, device=dev),
+                             palette=torch.zeros((n, j, 16), dtype=torch.float32, device=dev)))
+        torch.cuda.synchronize()
+        frame = make_frame(s["planes"], s["cam_pos"])
+        for k in range(8):  # A, B, A, B ... queued without waiting
+            o = outs[k % 2]
+            p.set_poses_device(bufs[k % 2].data_ptr(), n)
+            p.run_skinned(frame, palette=o["palette"].data_ptr(), draw_cmds=o["cmds"].data_ptr(), draw_count=o["scal"].data_ptr(),
+                          draw_index_total=o["scal"].data_ptr() + 4, async_=True)
+        p.wait()
+        for o, w in zip(outs, wants):
+            count = int(o["scal"][0].item())
+            assert count == w["draw_count"] and o["cmds"][:count].cpu().numpy().tobytes() == w["draw_cmds"].tobytes()
+            assert len(float_mismatches(o["palette"].cpu().numpy(), w["palette"])) == 0
+
+
 def test_frames_in_flight_and_errors(ra, oracle_mod):
     import torch
 
