@@ -1115,7 +1115,12 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   local.draw_index_total = ctx->d_send + 1;
   local.draw_cmds = ctx->d_send + sizeof(MipShardHeader) / 4;
   local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC;
+  // kernel, all-gather and merge are ordered by ONE stream and share one send/receive buffer: a sharded
+  // frame always takes frame slot 0 (= ctx->stream), whatever frames_in_flight is. Overlapping sharded
+  // frames is done with several contexts (renderer_amd/sharded.py, PipelinedExchange).
+  ctx->next_slot = 0;
   if (int32_t rc = mip_run(ctx, frame, &local)) return rc;
+  ctx->next_slot = 0;
   // 2. ONE all-gather of the fixed-size chunks, 3. merge — same stream, no host round trip
   const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
   if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
