@@ -296,8 +296,11 @@ int32_t mip_wait(MipContext* ctx);
  * chunks `chunk_stride_bytes` apart, as an all-gather lays them out; DEVICE memory) into
  * one contiguous list in shard order, adding to each shard's firstIndex the
  * draw_index_total of all earlier shards. out_count[0] = total commands,
- * out_count[1] = total indices (so out_count needs room for 2 words). DEVICE pointers. Enqueued on the context's stream; synchronous unless
- * `async` is non-zero. `out_cmds` needs room for the sum of the counts. */
+ * out_count[1] = total indices (so out_count needs room for 2 words). DEVICE pointers. Enqueued on the
+ * context's first stream (MipConfig.stream, or frame slot 0's): it is ordered after a frame of the same
+ * context only when frames_in_flight == 1 — use one context per frame in flight for sharded frames, as
+ * mip_run_sharded and renderer_amd/sharded.py do. Synchronous unless `async` is non-zero. `out_cmds`
+ * needs room for the sum of the counts. */
 int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks,
                              uint64_t chunk_stride_bytes, void* out_cmds, uint32_t* out_count,
                              int32_t async);
