@@ -359,6 +359,26 @@ def test_three_million_instances_multi_window_prefix(ra, oracle_mod):
     assert_parity(got, want, "3M")
 
 
+def test_plain_c_host(ra):
+    """integration/c/mip_smoke.c: a C99 program that links the library and runs a frame with host pointers —
+    the boundary as the reference-side shim would use it."""
+    import os
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "renderer_amd", "lib")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "mip_smoke")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "integration", "c", "mip_smoke.c"), "-L", lib_dir, "-lmi_instance_pipeline",
+                               "-Wl,-rpath," + lib_dir, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "C_SMOKE OK" in out.stdout, out.stdout + out.stderr
+    fields = dict(x.split("=") for x in out.stdout.split()[2:])
+    assert 0 < int(fields["commands"]) == int(fields["visible"]) < 1000
+
+
 def test_ordered_tiles_variant(ra, oracle_mod):
     """MIP_CFG_ORDERED_TILES: tile numbers come from a counter (no assumption about the order workgroups
     start in). Same results, for the plain frame, frames in flight, recorded launch graphs and a skinned
