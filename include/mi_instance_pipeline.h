@@ -288,6 +288,18 @@ int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_
  * culled_index_buffer is not supported (the per-triangle stage does not skin vertices). */
 int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, void* palette);
 
+/* Several views of the resident instances in ONE launch — per-light culled draw lists (the shadow pass
+ * with a frustum per light), cascades, cube faces, stereo. View v is a complete cull_pass with
+ * frames[v]'s planes, LOD reference point (cam_pos) and bases, and gives exactly what mip_run would give
+ * for that frame: outs[v].visible_bitmap (optional), outs[v].draw_cmds + draw_count (required),
+ * outs[v].draw_index_total (optional). The instance data is read once and the model matrix / world box
+ * built once for all views; nothing view-independent is written, so model, world_aabb, tlas_instances
+ * and culled_index_buffer must be NULL (run the frame's mip_run for those). 1 <= n_views <=
+ * MIP_MAX_VIEWS; every output set carries MIP_OUT_DEVICE; the launch is asynchronous if outs[0] carries
+ * MIP_OUT_ASYNC. Runs on the context's first stream. */
+#define MIP_MAX_VIEWS 4
+int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views);
+
 /* Block until everything enqueued by this context has finished; reports a
  * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
 int32_t mip_wait(MipContext* ctx);

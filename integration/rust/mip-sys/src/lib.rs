@@ -113,6 +113,8 @@ extern "C" {
                             n_joints: u32) -> i32;
     pub fn mip_set_poses(ctx: *mut MipContext, joint_trs: *const c_void, n: u32, device: i32) -> i32;
     pub fn mip_run_skinned(ctx: *mut MipContext, frame: *const MipFrame, out: *const MipOutputs, palette: *mut c_void) -> i32;
+    /// Up to 4 culled views (per-light lists, cascades) of the resident instances in one launch.
+    pub fn mip_run_views(ctx: *mut MipContext, frames: *const MipFrame, outs: *const MipOutputs, n_views: u32) -> i32;
     pub fn mip_comm_unique_id(out_id: *mut u8) -> i32;
     pub fn mip_comm_init(ctx: *mut MipContext, id: *const u8, rank: u32, world: u32) -> i32;
     pub fn mip_comm_destroy(ctx: *mut MipContext) -> i32;

@@ -27,7 +27,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -161,6 +161,8 @@ def load_library():
     lib.mip_set_poses.restype = C.c_int32
     lib.mip_run_skinned.argtypes = [vp, vp, vp, vp]
     lib.mip_run_skinned.restype = C.c_int32
+    lib.mip_run_views.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.mip_run_views.restype = C.c_int32
     lib.mip_comm_unique_id.argtypes = [vp]
     lib.mip_comm_unique_id.restype = C.c_int32
     lib.mip_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]

@@ -347,8 +347,11 @@ __device__ __forceinline__ unsigned long long status_load(const unsigned long lo
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by ONE lane of the tile once its aggregate is known.
-__device__ __forceinline__ void publish_aggregate(const KernelArgs& a, uint32_t tile, uint32_t count, uint32_t sum) {
+// Called by ONE lane of the tile once its aggregate is known. `A` is anything that carries a prefix
+// state: status0, acc1, start1, groups_cap, group_shift, epoch, error_flag (KernelArgs, or one view
+// of the multi-view kernel).
+template <class A>
+__device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uint32_t count, uint32_t sum) {
   const unsigned long long granule = ((unsigned long long)sum << 32) | ((unsigned long long)a.epoch << kTileCountBits) | count;
   __hip_atomic_store(&a.status0[tile], granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t group = tile >> a.group_shift;
@@ -369,7 +372,8 @@ constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators
 // entry read here is 64 groups = thousands of tiles back, i.e. long resolved, so the look-up
 // stays ONE round of <= 63 + 64 + 1 words for any N (without it every tile would read every
 // earlier group: quadratic, measured +100 us at 10 M instances).
-__device__ __forceinline__ void resolve_prefix(const KernelArgs& a, uint32_t tile, uint32_t lane,
+template <class A>
+__device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32_t lane,
                                                uint32_t& base_count, uint32_t& base_sum) {
   const uint32_t group = tile >> a.group_shift;
   const uint32_t group_first = group << a.group_shift;

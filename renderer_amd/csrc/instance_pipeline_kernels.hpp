@@ -7,3 +7,4 @@
 #include "triangle_kernels.hpp"      // row f-1: per-triangle cull + index-stream append, re-compaction
 #include "light_lists_kernel.hpp"    // row f-4: per-light shadow-pass draw lists
 #include "skinning_kernel.hpp"       // extension (BASELINE config 5): joint palette + posed box
+#include "views_kernel.hpp"          // row f-4: up to four culled views (per-light lists, cascades) in one launch

@@ -65,6 +65,7 @@ struct MipContext {
   uint32_t graph_round = 64;          // frames per replay round over all slots (MIP_TUNE_GRAPH_ROUND, 0 = off)
   std::vector<FrameSlot> slots;
   uint32_t next_slot = 0;
+  std::vector<FrameSlot> view_states;  // mip_run_views: one prefix state per view, all on `stream`
   hipStream_t stream = nullptr;  // = slots[0].stream: uploads, merges, timing
   // resident inputs
   float* d_pos = nullptr;
@@ -167,6 +168,7 @@ int32_t check_device_error(MipContext* ctx) {
       // the frame's prefix state is half-written: clear it before the next launch, and from now on
       // number the tiles from a counter, which cannot stall on the order workgroups start in
       for (auto& sl : ctx->slots) sl.status_dirty = true;
+      for (auto& sl : ctx->view_states) sl.status_dirty = true;
       ctx->ordered_tiles = true;
       ctx->graph_generation++;
       return fail(ctx, MIP_ERR_TIMEOUT,
@@ -305,6 +307,7 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_indices);
   (void)hipFree(ctx->d_joints);
   (void)hipFree(ctx->d_poses_owned);
+  for (auto& sl : ctx->view_states) (void)hipFree(sl.d_status);
   for (auto& sl : ctx->slots) {
     (void)hipFree(sl.d_status);
     (void)hipFree(sl.d_scalars);
@@ -511,6 +514,7 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
   }
   if (n != ctx->n) {
     for (auto& sl : ctx->slots) sl.status_dirty = true;  // tile/group geometry changes with n
+    for (auto& sl : ctx->view_states) sl.status_dirty = true;
     ctx->graph_generation++;                             // and so does every recorded launch
   }
   ctx->n = n;
@@ -876,6 +880,79 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
 int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   return run_frame(ctx, frame, out, false, nullptr);
+}
+
+int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!frames || !outs) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frames/outs is NULL");
+  static_assert(MIP_MAX_VIEWS == mip::kMaxViews, "view limit");
+  if (n_views == 0 || n_views > MIP_MAX_VIEWS) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_views %u outside 1..%u", n_views, (unsigned)MIP_MAX_VIEWS);
+  if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
+  for (uint32_t v = 0; v < n_views; ++v) {
+    const MipOutputs& o = outs[v];
+    if (!(o.flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "view %u: mip_run_views needs MIP_OUT_DEVICE outputs", v);
+    if (!o.draw_cmds || !o.draw_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "view %u: draw_cmds and draw_count are required", v);
+    if (o.model || o.world_aabb || o.tlas_instances || o.culled_index_buffer)
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "view %u: only visible_bitmap, draw_cmds, draw_count and draw_index_total are per view", v);
+  }
+  if (int32_t rc = bind_device(ctx)) return rc;
+  const uint32_t n = ctx->n;
+  const bool async = (outs[0].flags & MIP_OUT_ASYNC) != 0;
+  hipStream_t stream = ctx->stream;
+  if (n == 0) {
+    for (uint32_t v = 0; v < n_views; ++v) {
+      MIP_HIP(ctx, hipMemsetAsync(outs[v].draw_count, 0, 4, stream));
+      if (outs[v].draw_index_total) MIP_HIP(ctx, hipMemsetAsync(outs[v].draw_index_total, 0, 4, stream));
+    }
+  } else {
+    if (ctx->view_states.empty()) {
+      ctx->view_states.resize(MIP_MAX_VIEWS);
+      for (auto& vs : ctx->view_states) {
+        vs.stream = stream;  // not owned
+        MIP_HIP(ctx, hipMalloc(&vs.d_status, ctx->status_bytes));
+        MIP_HIP(ctx, hipMemsetAsync(vs.d_status, 0, ctx->status_bytes, stream));
+      }
+    }
+    mip::ViewsArgs a{};
+    a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
+    a.meshes = ctx->d_meshes; a.mesh_draw = ctx->d_mesh_draw;
+    a.n = n;
+    a.n_tiles = tiles_for(n);
+    a.bitmap_words = (n + 31u) / 32u;
+    a.n_views = n_views;
+    for (uint32_t v = 0; v < n_views; ++v) {
+      MipContext::FrameSlot& vs = ctx->view_states[v];
+      if (int32_t rc = reset_prefix_state_if_needed(ctx, vs, 2)) return rc;
+      uint32_t e = vs.epoch + 1;
+      if (vs.zero_buf != 2 && (e & 1u) != vs.zero_buf) ++e;
+      vs.epoch = vs.last_tag = e;
+      vs.zero_buf = (e & 1u) ^ 1u;
+      mip::ViewArgs& w = a.view[v];
+      w.status0 = vs.d_status;
+      w.acc1 = vs.d_status + ctx->acc1_offset_words;
+      w.start1 = vs.d_status + ctx->start1_offset_words;
+      w.groups_cap = ctx->groups_cap;
+      w.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
+      w.epoch = e;
+      w.error_flag = ctx->d_error;
+      w.bitmap = outs[v].visible_bitmap;
+      w.cmds = (uint32_t*)outs[v].draw_cmds;
+      w.draw_count = outs[v].draw_count;
+      w.index_total = outs[v].draw_index_total;
+      w.first_instance_base = frames[v].first_instance_base;
+      w.first_index_base = frames[v].first_index_base;
+      std::memcpy(w.planes, frames[v].planes, sizeof w.planes);
+      std::memcpy(w.cam, frames[v].cam_pos, sizeof w.cam);
+    }
+    hipLaunchKernelGGL(mip::mip_cull_views_kernel, dim3(a.n_tiles), dim3(mip::kTile), 0, stream, a);
+    MIP_HIP(ctx, hipGetLastError());
+  }
+  if (async) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  MIP_HIP(ctx, hipStreamSynchronize(stream));
+  return check_device_error(ctx);
 }
 
 int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* inverse_bind, const float* joint_box,

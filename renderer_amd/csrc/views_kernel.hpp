@@ -1,0 +1,180 @@
+// views_kernel.hpp — several frusta over the same instances in ONE launch (gfx950): per-light culled draw
+// lists (SURVEY.md section 8 f-4 "per-light cull lists"), shadow cascades, cube faces, stereo.
+#pragma once
+
+#include "instance_kernel.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mip {
+
+// Each view is a complete cull_pass over the resident instances — its own six planes
+// (cull_pipeline.rs:99-120), its own LOD reference point (pick_lod, helpers.rs:3-11), its own compacted
+// VkDrawIndexedIndirectCommand stream, count and visibility bitmap — with exactly the results of one
+// mip_run per view. What the views share is everything that does not depend on the frustum: the 36
+// bytes of instance data are read once, and the model matrix and world AABB (rows a-1, a-2) are built
+// once per instance instead of once per view. Up to four views per launch: view v's cross-tile prefix
+// (same one-hop scheme as the instance kernel, one state per view) is resolved and its commands copied
+// out by wave v of the workgroup, so the four hops run side by side. The matrices are not written here
+// (they do not depend on the view; the frame's mip_run writes them).
+constexpr uint32_t kMaxViews = 4;
+
+struct ViewArgs {
+  // prefix state of this view (publish_aggregate / resolve_prefix read these names)
+  unsigned long long* status0;
+  unsigned long long* acc1;
+  unsigned long long* start1;
+  uint32_t groups_cap;
+  uint32_t group_shift;
+  uint32_t epoch;
+  uint32_t* error_flag;
+#ifdef MIP_DEBUG_STAMPS
+  unsigned long long* stamps;  // never set: keeps the shared prefix routines compiling in the diagnostic build
+#endif
+  // outputs
+  uint32_t* bitmap;       // ceil(n/32) words or null
+  uint32_t* cmds;         // n*5 words
+  uint32_t* draw_count;
+  uint32_t* index_total;  // or null
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  float planes[24];
+  float cam[3];
+};
+
+struct ViewsArgs {
+  const float* pos;
+  const float4* rot;
+  const float* scale;
+  const uint32_t* mesh_id;
+  const MeshEntry* meshes;
+  const MeshDraw* mesh_draw;
+  uint32_t n;
+  uint32_t n_tiles;
+  uint32_t bitmap_words;
+  uint32_t n_views;
+  ViewArgs view[kMaxViews];
+};
+
+__global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArgs a) {
+  __shared__ uint32_t s_cmd[kMaxViews][kTile * kCmdWords];
+  __shared__ uint32_t s_wave_count[kMaxViews][kWaves], s_wave_sum[kMaxViews][kWaves];
+  static_assert(kWaves >= kMaxViews, "one wave per view finishes that view");
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tile_first = tile * kTile;
+  const uint32_t i = tile_first + tid;
+  const bool active = i < a.n;
+  const uint32_t il = active ? i : a.n - 1u;
+
+  // ---- shared by all views: loads, model matrix, world AABB (as the instance kernel) ----
+  const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
+  const float4 q = a.rot[il];
+  const float sc = a.scale[il];
+  const uint32_t mesh = a.mesh_id[il];
+  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
+  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  MeshEntry mb;
+  mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
+  mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
+  const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
+  float r[3][3];
+  quat_to_rotation(q.x, q.y, q.z, q.w, r);
+  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  Instance inst;
+  if (__builtin_expect(__any(!(mag < 3.0e38f)), 0)) {
+    instance_general(r, px, py, pz, sc, mb, inst);
+  } else {
+    instance_fast(r, px, py, pz, sc, mb, inst);
+  }
+
+  // ---- per view: frustum test, LOD, wave-level compaction offsets ----
+  bool keep[kMaxViews];
+  uint32_t len[kMaxViews], rank[kMaxViews], excl_sum[kMaxViews];
+  unsigned long long vis_mask[kMaxViews];
+  (void)md.y;
+#pragma unroll
+  for (uint32_t v = 0; v < kMaxViews; ++v) {
+    keep[v] = false; len[v] = 0; rank[v] = 0; excl_sum[v] = 0; vis_mask[v] = 0;
+    if (v < a.n_views) {
+      const bool visible = active && !coarse_culled(inst, a.view[v].planes);
+      const float dx = a.view[v].cam[0] - px, dy = a.view[v].cam[1] - py, dz = a.view[v].cam[2] - pz;
+      const float dist_sq = dx * dx + dy * dy + dz * dz;
+      const bool far_lod = dist_sq > kLodDistSqThreshold;
+      len[v] = far_lod ? mb.len1 : mb.len0;
+      keep[v] = visible && len[v] > 0u;
+      const uint32_t len_vis = visible ? len[v] : 0u;
+      const unsigned long long keep_mask = __ballot(keep[v]);
+      vis_mask[v] = __ballot(visible);
+      rank[v] = lanes_below(keep_mask);
+      const uint32_t incl = wave_inclusive_scan(len_vis);
+      excl_sum[v] = incl - len_vis;
+      if (lane == 63u) {
+        s_wave_count[v][wave] = (uint32_t)__popcll(keep_mask);
+        s_wave_sum[v][wave] = incl;
+      }
+      // visibility bitmap: one 64-bit ballot per wave, written as two words
+      if (a.view[v].bitmap && lane < 2u) {
+        const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
+        if (word < a.bitmap_words) a.view[v].bitmap[word] = (uint32_t)(vis_mask[v] >> (32u * lane));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- tile aggregates: thread v publishes view v ----
+  if (tid < a.n_views) {
+    uint32_t c = 0, s = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) { c += s_wave_count[tid][w]; s += s_wave_sum[tid][w]; }
+    publish_aggregate(a.view[tid], tile, c, s);
+  }
+
+  // ---- tile-local command assembly, every view ----
+#pragma unroll
+  for (uint32_t v = 0; v < kMaxViews; ++v) {
+    if (v < a.n_views && keep[v]) {
+      uint32_t off_count = 0, off_sum = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kWaves; ++w)
+        if (w < wave) { off_count += s_wave_count[v][w]; off_sum += s_wave_sum[v][w]; }
+      uint32_t* c = &s_cmd[v][(off_count + rank[v]) * kCmdWords];
+      c[0] = len[v];                                // indexCount
+      c[1] = 1u;                                    // instanceCount
+      c[2] = off_sum + excl_sum[v];                 // firstIndex (tile-relative)
+      c[3] = md.x;                                  // vertexOffset
+      c[4] = a.view[v].first_instance_base + i;     // firstInstance = draw_index
+    }
+  }
+  __syncthreads();
+
+  // ---- wave v finishes view v: prefix over the earlier tiles, coalesced copy-out ----
+  const uint32_t my_view = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);  // scalar: the view's words are scalar loads
+  if (my_view >= a.n_views) return;
+  const ViewArgs& view = a.view[my_view];
+  uint32_t tile_count = 0, tile_sum = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kWaves; ++w) { tile_count += s_wave_count[my_view][w]; tile_sum += s_wave_sum[my_view][w]; }
+  uint32_t base_count = 0, base_sum = 0;
+  if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum);
+  if (lane == 0 && tile == a.n_tiles - 1u) {
+    *view.draw_count = base_count + tile_count;
+    if (view.index_total) *view.index_total = base_sum + tile_sum;
+  }
+  const uint32_t first_index_add = base_sum + view.first_index_base;
+  uint32_t* out = view.cmds + (size_t)base_count * kCmdWords;
+  const uint32_t words = tile_count * kCmdWords;
+  for (uint32_t j = lane; j < words; j += 64u) {
+    const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
+    uint32_t val = s_cmd[my_view][j];
+    if (f == 2u) val += first_index_add;
+    out[j] = val;
+  }
+}
+
+}  // namespace mip

@@ -287,6 +287,17 @@ class InstancePipeline:
         if rc != 0:
             self._check(rc)
 
+    def run_views(self, frames, prepared_outputs):
+        """Up to 4 views (per-light culled lists, cascades ...) of the resident instances in one launch:
+        frames[v] (make_frame) with prepared_outputs[v] (prepare_outputs: bitmap / draw_cmds / draw_count / index total)."""
+        k = len(frames)
+        fr = (MipFrame * k)()
+        ou = (MipOutputs * k)()
+        for v in range(k):
+            C.memmove(C.addressof(fr[v]), C.addressof(frames[v]), C.sizeof(MipFrame))
+            C.memmove(C.addressof(ou[v]), C.addressof(prepared_outputs[v]), C.sizeof(MipOutputs))
+        self._check(self._lib.mip_run_views(self._ctx, C.addressof(fr), C.addressof(ou), k))
+
     def light_draw_lists(self, light_pos_xyz, out_cmds_ptr, first_instance_base=0, async_=False):
         """Per-light shadow-pass draw lists (shadow_mapping.rs:405-478): n_lights x n commands, light-major,
         into device memory at out_cmds_ptr."""

@@ -514,6 +514,100 @@ def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):
         ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=99)
 
 
+def test_per_light_culled_lists_as_concurrent_views(ra, oracle_mod):
+    """SURVEY section 8 f-4 "per-light cull lists": one view per light — the light's own six planes and its
+    position as the LOD reference — queued back to back on a context with as many frame slots as lights,
+    so the views overlap on the device. Every view's bitmap and list must be the oracle's for that view."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=200_000)
+    rng = np.random.default_rng(21)
+    lights = [np.array(p, np.float32) for p in ((30, 20, -40.1), (0.1, 17, 0.1), (-20, 5, 10), (0, 40, 0))]  # main.rs:368-382 + two
+    views = []
+    for lp in lights:
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        views.append((lp, oracle_mod.project_camera(lp, q.astype(np.float32), aspect=1.0, fovy_degrees=90.0, near=0.5, far=200.0)))
+    dev = torch.device("cuda", 0)
+    n = s["n"]
+    with ra.InstancePipeline(max_instances=n, max_meshes=64, frames_in_flight=len(views)) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        bufs = [(torch.zeros((n, 5), dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev),
+                 torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)) for _ in views]
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for (lp, planes), (cmds, scal, bitmap) in zip(views, bufs):
+                p.run_device(make_frame(planes, lp), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                             draw_index_total=scal.data_ptr() + 4, visible_bitmap=bitmap.data_ptr(), async_=True)
+        p.wait()
+        counts = []
+        for (lp, planes), (cmds, scal, bitmap) in zip(views, bufs):
+            want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], planes, lp, threads=8,
+                                  want=("draw_cmds", "visible_bitmap"))
+            count = int(scal[0].item())
+            counts.append(count)
+            assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+            assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
+        assert len(set(counts)) > 1 and all(0 < c < n for c in counts)  # the views do differ
+
+
+def test_run_views_matches_one_run_per_view(ra, oracle_mod):
+    """mip_run_views: 1..4 frusta over the same instances in one launch (per-light culled lists). Every view
+    must be byte-identical to the oracle's frame for that view — including bases, non-finite instances,
+    partial tiles, an empty scene, repeated launches — and the argument checks must hold."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    rng = np.random.default_rng(33)
+    dev = torch.device("cuda", 0)
+    for n, k in ((0, 2), (1, 1), (255, 3), (70_001, 4), (1_000_000, 4)):
+        s = ra.scene.make_scene(3, n=max(n, 1))
+        if n == 0:
+            s = {key: (val[:0] if isinstance(val, np.ndarray) and key in ("pos", "rot", "scale", "mesh_id") else val) for key, val in s.items()}
+        if n > 100:
+            s["pos"][17] = np.nan
+            s["scale"][33] = np.inf
+        views = []
+        for v in range(k):
+            lp = rng.normal(0, 15, 3).astype(np.float32)
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            planes = oracle_mod.project_camera(lp, q.astype(np.float32), aspect=float(rng.uniform(0.8, 2)), fovy_degrees=float(rng.uniform(50, 110)),
+                                               near=0.2, far=300.0)
+            views.append((lp, planes, int(rng.integers(0, 1000)), int(rng.integers(0, 2 ** 32))))
+        with ra.InstancePipeline(max_instances=max(n, 1), max_meshes=64) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            bufs = [(torch.full((max(n, 1), 5), -1, dtype=torch.int32, device=dev), torch.full((8,), -1, dtype=torch.int32, device=dev),
+                     torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=dev)) for _ in views]
+            torch.cuda.synchronize()
+            frames = [make_frame(pl, lp, first_instance_base=fib, first_index_base=fxb) for lp, pl, fib, fxb in views]
+            outs = [p.prepare_outputs(draw_cmds=c.data_ptr(), draw_count=sc.data_ptr(), draw_index_total=sc.data_ptr() + 4,
+                                      visible_bitmap=b.data_ptr(), async_=False) for c, sc, b in bufs]
+            for rep in range(3):
+                p.run_views(frames, outs)
+            for (lp, pl, fib, fxb), (cmds, scal, bitmap) in zip(views, bufs):
+                want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], pl, lp, first_instance_base=fib,
+                                      first_index_base=fxb, threads=8, want=("draw_cmds", "visible_bitmap"))
+                count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+                assert count == want["draw_count"] and total == want["draw_index_total"], (n, k)
+                assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), (n, k)
+                assert np.array_equal(bitmap[:(n + 31) // 32].cpu().numpy().view(np.uint32), want["visible_bitmap"]), (n, k)
+            if n == 255:
+                with pytest.raises(ra.MipError):
+                    p.run_views(frames + frames, outs + outs)              # more than 4 views
+                model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+                with pytest.raises(ra.MipError):                           # matrices are not per view
+                    p.run_views(frames[:1], [p.prepare_outputs(model=model.data_ptr(), draw_cmds=bufs[0][0].data_ptr(),
+                                                               draw_count=bufs[0][1].data_ptr(), async_=False)])
+                with pytest.raises(ra.MipError):                           # a view needs its command list
+                    p.run_views(frames[:1], [p.prepare_outputs(visible_bitmap=bufs[0][2].data_ptr(), async_=False)])
+
+
 def test_tlas_instance_rows(ra, oracle_mod):
     """Row f-4: VkAccelerationStructureInstanceKHR rows for every instance, with and without the
     matrix output, with BLAS addresses and a draw_index base."""
