@@ -67,6 +67,31 @@ for seed in range(first, first + seeds):
             wl = oracle.light_draw_lists(s["pos"], s["mesh_id"], s["meshes"], lights, first_instance_base=fib)
             if out.cpu().numpy()[:-1].tobytes() != wl.tobytes():
                 fail(seed, f"light lists n={n} lights={len(lights)}")
+            # several culled views in one launch
+            k = int(rng.integers(1, 5))
+            vw = []
+            for _ in range(k):
+                lp = rng.normal(0, 20, 3).astype(np.float32)
+                qq = rng.normal(size=4)
+                qq /= np.linalg.norm(qq)
+                pl = oracle.project_camera(lp, qq.astype(np.float32), aspect=float(rng.uniform(0.5, 3)), fovy_degrees=float(rng.uniform(20, 120)),
+                                           near=float(rng.uniform(0.01, 1)), far=float(rng.uniform(10, 1000)))
+                if rng.random() < 0.2:
+                    pl[rng.integers(0, 24, 2)] = rng.choice(SPECIAL, 2)
+                vw.append((lp, pl, int(rng.integers(0, 2 ** 32)), int(rng.integers(0, 2 ** 32))))
+            vb = [(torch.zeros((n, 5), dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev),
+                   torch.zeros((n + 31) // 32, dtype=torch.int32, device=dev)) for _ in vw]
+            torch.cuda.synchronize()
+            p.run_views([make_frame(pl, lp, first_instance_base=a, first_index_base=b) for lp, pl, a, b in vw],
+                        [p.prepare_outputs(draw_cmds=c.data_ptr(), draw_count=sc.data_ptr(), draw_index_total=sc.data_ptr() + 4,
+                                           visible_bitmap=bm.data_ptr(), async_=False) for c, sc, bm in vb])
+            for (lp, pl, a, b), (c, sc, bm) in zip(vw, vb):
+                wv = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], pl, lp, first_instance_base=a, first_index_base=b,
+                                threads=8, want=("draw_cmds", "visible_bitmap"))
+                cnt, tot = (int(x) & 0xFFFFFFFF for x in sc[:2].cpu().tolist())
+                if not (cnt == wv["draw_count"] and tot == wv["draw_index_total"] and c[:cnt].cpu().numpy().tobytes() == wv["draw_cmds"].tobytes()
+                        and np.array_equal(bm.cpu().numpy().view(np.uint32), wv["visible_bitmap"])):
+                    fail(seed, f"run_views n={n} views={k}")
             # skinned frame
             j = int(rng.integers(1, 33))
             sk = random_skeleton(rng, j)
