@@ -210,6 +210,43 @@ def light_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
     }
 
 
+def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
+    """Row f-4, "per-light cull lists": four culled views (the reference's light positions as LOD reference
+    points, the default frustum moved to each) of the headline scene in one launch, mip_run_views."""
+    n = s["n"]
+    p = renderer_amd.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), device=local_rank)
+    p.set_mesh_table(s["meshes"])
+    p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    eyes = np.array([[0, 1, 2], [30, 20, -40.1], [0.1, 17, -0.1], [-30, 20, 40.1]], np.float32)
+    frames, outs, keep = [], [], []
+    for e in eyes:
+        planes = s["planes"].copy()
+        # the default frustum translated to the eye: d' = d - n . (eye - default eye)
+        shift = e - np.asarray(s["cam_pos"], np.float32)
+        planes.reshape(6, 4)[:, 3] -= planes.reshape(6, 4)[:, :3] @ shift
+        cmds = torch.empty((n, 5), dtype=torch.int32, device=device)
+        scal = torch.zeros(8, dtype=torch.int32, device=device)
+        bitmap = torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=device)
+        keep.append((cmds, scal, bitmap))
+        frames.append(make_frame(planes, e))
+        outs.append(p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4,
+                                      visible_bitmap=bitmap.data_ptr()))
+    torch.cuda.synchronize()
+    for _ in range(20):
+        p.run_views(frames, outs)
+    p.wait()
+    counts = [int(k[1][0].item()) for k in keep]
+    t0 = time.perf_counter()
+    for _ in range(300):
+        p.run_views(frames, outs)
+    p.wait()
+    dt = (time.perf_counter() - t0) / 300
+    p.close()
+    return {"instances": n, "views": len(eyes), "ms_per_launch": dt * 1e3, "instance_views_per_s": n * len(eyes) / dt,
+            "commands_per_view": counts,
+            "note": "one launch: instance data read once, matrix + world box built once, per view plane test + compaction"}
+
+
 def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_rank):
     """BASELINE config 5 (extension, no reference semantics): 256 k instances of a 19-joint figure, each
     with its own pose: palette + skinned bounds kernel, then the instance kernel."""
@@ -535,7 +572,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             result.setdefault("extra", {})["triangle_cull"] = {"error": f"{type(e).__name__}: {e}"}
 
-        for label, leg in (("light_draw_lists", light_leg), ("skinned_256k", skinned_leg)):
+        for label, leg in (("light_draw_lists", light_leg), ("culled_views_x4", views_leg), ("skinned_256k", skinned_leg)):
             try:  # an extra leg must never cost the headline line
                 result["extra"][label] = leg(torch, renderer_amd, scene, make_frame, s, device, local_rank)
             except Exception as e:  # noqa: BLE001
