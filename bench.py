@@ -578,6 +578,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["extra"][label] = {"error": f"{type(e).__name__}: {e}"}
 
+    watchdog = None
+    if distributed and not args.no_extra:
+        # The secondary leg below is the first code of this run with a real data-path collective. If a rank
+        # fails inside it the others would sit in the all-gather until NCCL's own timeout (10 min) and the
+        # headline line would never be printed: a watchdog prints it without the leg and ends the process.
+        import threading
+
+        def bail():
+            if rank == 0:
+                result.setdefault("extra", {})["sharded_exchange"] = {"error": "secondary leg did not finish within 120 s; abandoned"}
+                os.write(json_fd, (json.dumps(result) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(120.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if distributed and not args.no_extra:
         try:
             # the exchange regime (BASELINE config 4's shape): 1.25 M instances per rank, one RCCL
@@ -663,6 +679,8 @@ def main():
     pipe.close()
     if distributed:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
