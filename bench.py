@@ -526,6 +526,28 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(s, args.cpu_seconds)
 
+    # Everything below is reported beside the headline. If a secondary leg stalls — a rank failing inside
+    # the multi-rank leg would leave the others in the all-gather until NCCL's own 10-minute timeout — the
+    # headline line must still come out: a watchdog prints it with what is there and ends the process.
+    watchdog = None
+    if not args.no_extra:
+        import threading
+
+        def bail():
+            try:
+                if rank == 0:
+                    try:
+                        line = json.dumps(dict(result, watchdog="secondary legs did not finish within 240 s; abandoned"))
+                    except Exception:  # noqa: BLE001  (the main thread was writing into `extra`)
+                        line = json.dumps({k: v for k, v in result.items() if k != "extra"})
+                    os.write(json_fd, (line + "\n").encode())
+            finally:
+                os._exit(0)
+
+        watchdog = threading.Timer(240.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     if not args.no_extra and not distributed and args.config == 2 and args.instances is None:
         # secondary regimes (not the headline): 1 M instances, HBM-bound; and all-visible
         extra = {}
@@ -578,22 +600,6 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["extra"][label] = {"error": f"{type(e).__name__}: {e}"}
 
-    watchdog = None
-    if distributed and not args.no_extra:
-        # The secondary leg below is the first code of this run with a real data-path collective. If a rank
-        # fails inside it the others would sit in the all-gather until NCCL's own timeout (10 min) and the
-        # headline line would never be printed: a watchdog prints it without the leg and ends the process.
-        import threading
-
-        def bail():
-            if rank == 0:
-                result.setdefault("extra", {})["sharded_exchange"] = {"error": "secondary leg did not finish within 120 s; abandoned"}
-                os.write(json_fd, (json.dumps(result) + "\n").encode())
-            os._exit(0)
-
-        watchdog = threading.Timer(120.0, bail)
-        watchdog.daemon = True
-        watchdog.start()
     if distributed and not args.no_extra:
         try:
             # the exchange regime (BASELINE config 4's shape): 1.25 M instances per rank, one RCCL
@@ -679,9 +685,9 @@ def main():
     pipe.close()
     if distributed:
         dist.barrier()
-        if watchdog is not None:
-            watchdog.cancel()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
