@@ -295,9 +295,10 @@ int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs
  * outs[v].draw_index_total (optional). The instance data is read once and the model matrix / world box
  * built once for all views; nothing view-independent is written, so model, world_aabb, tlas_instances
  * and culled_index_buffer must be NULL (run the frame's mip_run for those). 1 <= n_views <=
- * MIP_MAX_VIEWS; every output set carries MIP_OUT_DEVICE; the launch is asynchronous if outs[0] carries
- * MIP_OUT_ASYNC. Runs on the context's first stream. */
-#define MIP_MAX_VIEWS 4
+ * MIP_MAX_VIEWS (the 4 x 4 shadow atlas, shadow_mapping.rs:24); four views share a launch, more views
+ * are further launches on the same stream. Every output set carries MIP_OUT_DEVICE; the call is
+ * asynchronous if outs[0] carries MIP_OUT_ASYNC. Runs on the context's first stream. */
+#define MIP_MAX_VIEWS 16
 int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views);
 
 /* Block until everything enqueued by this context has finished; reports a

@@ -882,11 +882,8 @@ int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   return run_frame(ctx, frame, out, false, nullptr);
 }
 
-int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views) {
-  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views, bool async) {
   if (!frames || !outs) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frames/outs is NULL");
-  static_assert(MIP_MAX_VIEWS == mip::kMaxViews, "view limit");
-  if (n_views == 0 || n_views > MIP_MAX_VIEWS) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_views %u outside 1..%u", n_views, (unsigned)MIP_MAX_VIEWS);
   if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
   for (uint32_t v = 0; v < n_views; ++v) {
     const MipOutputs& o = outs[v];
@@ -897,7 +894,6 @@ int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs*
   }
   if (int32_t rc = bind_device(ctx)) return rc;
   const uint32_t n = ctx->n;
-  const bool async = (outs[0].flags & MIP_OUT_ASYNC) != 0;
   hipStream_t stream = ctx->stream;
   if (n == 0) {
     for (uint32_t v = 0; v < n_views; ++v) {
@@ -906,7 +902,7 @@ int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs*
     }
   } else {
     if (ctx->view_states.empty()) {
-      ctx->view_states.resize(MIP_MAX_VIEWS);
+      ctx->view_states.resize(mip::kMaxViews);
       for (auto& vs : ctx->view_states) {
         vs.stream = stream;  // not owned
         MIP_HIP(ctx, hipMalloc(&vs.d_status, ctx->status_bytes));
@@ -953,6 +949,20 @@ int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs*
   }
   MIP_HIP(ctx, hipStreamSynchronize(stream));
   return check_device_error(ctx);
+}
+
+int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!frames || !outs) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frames/outs is NULL");
+  if (n_views == 0 || n_views > MIP_MAX_VIEWS) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_views %u outside 1..%u", n_views, (unsigned)MIP_MAX_VIEWS);
+  const bool async = (outs[0].flags & MIP_OUT_ASYNC) != 0;
+  // four views per launch (one wave of a workgroup finishes one view); more views are more launches on the same stream
+  for (uint32_t first = 0; first < n_views; first += mip::kMaxViews) {
+    const uint32_t k = n_views - first < mip::kMaxViews ? n_views - first : mip::kMaxViews;
+    const bool last = first + k == n_views;
+    if (int32_t rc = run_views_chunk(ctx, frames + first, outs + first, k, async || !last)) return rc;
+  }
+  return MIP_OK;
 }
 
 int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* inverse_bind, const float* joint_box,

@@ -288,7 +288,7 @@ class InstancePipeline:
             self._check(rc)
 
     def run_views(self, frames, prepared_outputs):
-        """Up to 4 views (per-light culled lists, cascades ...) of the resident instances in one launch:
+        """Up to 16 views (per-light culled lists, cascades ...) of the resident instances, four per launch:
         frames[v] (make_frame) with prepared_outputs[v] (prepare_outputs: bitmap / draw_cmds / draw_count / index total)."""
         k = len(frames)
         fr = (MipFrame * k)()

@@ -564,7 +564,7 @@ def test_run_views_matches_one_run_per_view(ra, oracle_mod):
 
     rng = np.random.default_rng(33)
     dev = torch.device("cuda", 0)
-    for n, k in ((0, 2), (1, 1), (255, 3), (70_001, 4), (1_000_000, 4)):
+    for n, k in ((0, 2), (1, 1), (255, 3), (70_001, 4), (40_000, 7), (3000, 16), (1_000_000, 4)):
         s = ra.scene.make_scene(3, n=max(n, 1))
         if n == 0:
             s = {key: (val[:0] if isinstance(val, np.ndarray) and key in ("pos", "rot", "scale", "mesh_id") else val) for key, val in s.items()}
@@ -599,7 +599,7 @@ def test_run_views_matches_one_run_per_view(ra, oracle_mod):
                 assert np.array_equal(bitmap[:(n + 31) // 32].cpu().numpy().view(np.uint32), want["visible_bitmap"]), (n, k)
             if n == 255:
                 with pytest.raises(ra.MipError):
-                    p.run_views(frames + frames, outs + outs)              # more than 4 views
+                    p.run_views(frames * 6, outs * 6)                      # more than 16 views
                 model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
                 with pytest.raises(ra.MipError):                           # matrices are not per view
                     p.run_views(frames[:1], [p.prepare_outputs(model=model.data_ptr(), draw_cmds=bufs[0][0].data_ptr(),
