@@ -36,16 +36,18 @@ namespace mip {
 // Register budget: minimum waves per SIMD the kernel is compiled for (k workgroups of 256
 // threads per CU <=> k waves per SIMD). Overridable to build tuning variants.
 #ifndef MIP_MIN_WAVES_PER_SIMD
-#define MIP_MIN_WAVES_PER_SIMD 6
+#define MIP_MIN_WAVES_PER_SIMD 5
 #endif
 
 #ifndef MIP_TILE
 #define MIP_TILE 256
 #endif
+
 constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
+constexpr uint32_t kMeshCacheEntries = 128;  // mesh tables up to this size are read through LDS (32 B each, inside the command area)
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
 // len0 = index_len[0]; len1 = index_len[1] if n_lods > 1 else index_len[0]
@@ -93,6 +95,7 @@ struct KernelArgs {
   uint32_t n_tiles;
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
+  uint32_t n_meshes;            // mesh-table entries (tables of <= kMeshCacheEntries are staged in LDS)
   uint32_t first_instance_base;
   uint32_t first_index_base;
   float planes[24];
@@ -137,6 +140,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
+// 16-byte streaming store of an output that this launch never reads again: non-temporal
+// (global_store_dwordx4 ... nt). Measured on whole 1-KiB-per-instruction streams: the byte mover of
+// tools/micro/floor_1m.hip 17.1 -> 15.9 us at 1 M instances, this kernel 21.5 -> 20.0 us.
+__device__ __forceinline__ void store_stream16(float4* p, float4 v) {
+#ifndef MIP_EXP_NO_NT
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+#else
+  *p = v;
+#endif
 }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
@@ -452,26 +467,81 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
 // the kernel
 // ---------------------------------------------------------------------------------------
 
+// The finite test that selects the collapsed arithmetic (instance_fast): a sum of magnitudes is NaN/inf
+// as soon as one term is (or the sum overflows — then the literal path, exact for everything, runs).
+// ONE definition: the frame kernel's per-wave test and the upload-time census
+// (mip_count_nonfinite_kernel) that lets the host pick the kernel without a cold path must agree.
+__device__ __forceinline__ float finite_magnitude(const float (&r)[3][3], float px, float py, float pz, float sc) {
+  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  return mag;
+}
+constexpr float kFiniteLimit = 3.0e38f;
+
+// Upload-time census: how many instances of [first, first + count) fail the finite test. The
+// host keeps the total (mip_set_instances*, mip_update_instances); while it is zero the frame is
+// launched as mip_instance_pipeline_kernel<.., .., kGeneral = false>.
+struct CensusArgs {
+  const float* pos; const float4* rot; const float* scale;
+  uint32_t first, count;
+  uint32_t* out;  // += number of non-finite instances
+};
+__global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusArgs a) {
+  uint32_t bad = 0;
+  for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.count; k += gridDim.x * 256u) {
+    const size_t i = (size_t)a.first + k;
+    const float4 q = a.rot[i];
+    float r[3][3];
+    quat_to_rotation(q.x, q.y, q.z, q.w, r);
+    bad += finite_magnitude(r, a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2], a.scale[i]) < kFiniteLimit ? 0u : 1u;
+  }
+  bad = wave_sum(bad);
+  if ((threadIdx.x & 63u) == 0u && bad) atomicAdd(a.out, bad);
+}
+
+// Tile aggregate assembled in LDS by the four waves: {Σ index_len : 32 | arrivals : 8 | - : 8 | count : 16}.
+constexpr uint32_t kAggArrivalShift = 24;
+
 // kTicketedTiles: a workgroup's tile number comes from a ticket counter instead of blockIdx.x. Tiles
 // wait only for lower-numbered tiles, and a ticket is only ever held by a workgroup that is already
 // running, so the waits cannot deadlock whatever order the hardware starts workgroups in — at the
 // price of one atomic round trip at the head of every workgroup. The library switches to this
 // variant after a MIP_ERR_TIMEOUT (or with MIP_CFG_ORDERED_TILES); the default keeps blockIdx.x.
 // kBoxOverride: every instance brings its own mesh-space box (KernelArgs.box_override; the skinned
-// extension). A separate instantiation because the extra live values make the cold literal path spill
-// 16 bytes per lane, which the ordinary frame's kernel should not carry.
-template <bool kTicketedTiles, bool kBoxOverride>
-__global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pipeline_kernel(const KernelArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];     // rows 0..2 of every matrix
-  __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3
-  // The tile's commands (5 KB) reuse the staging area of waves 1-3 (9 KB) once those waves have
-  // stored their matrices: 13.6 KB of LDS per workgroup instead of 18.5 KB, so that more
-  // workgroups whose wave 0 is still waiting for its prefix fit beside the running ones.
-  uint32_t* const s_cmd = reinterpret_cast<uint32_t*>(&s_mat[64 * 12]);
+// extension).
+// kGeneral: the kernel carries the literal arithmetic chain for non-finite inputs (taken per wave).
+// That path costs 16 VGPRs (80 against 64: 6 against 8 waves per SIMD) whether it runs or not, so
+// the host launches <.., .., false> whenever its upload-time census found every instance finite
+// (mesh-table boxes always are); a per-instance box override may be non-finite, so it implies kGeneral.
+// kOrder: what a workgroup does between its arithmetic and its exit (both orders produce identical bytes).
+//   1  stores first: waves 1-3 store their matrices, THEN the commands are assembled (in the staging
+//      area those waves have just freed: 13.4 KB of LDS per workgroup) and wave 0 resolves the prefix,
+//      copies the commands out and stores its own matrices last. The store issue of waves 1-3 paces
+//      the polls; best once the launch has a steady state (>= 1 M instances: 191 vs 240 us at 10 M).
+//   3  commands first: assembly in an area of its own (19.5 KB), then waves 1-3 store all sixteen
+//      matrix pieces while wave 0 spends that time on the prefix round trip and the copy-out.
+//      Shortest dependency chain per tile; best while every tile is in the launch's first and last
+//      generation of workgroups (100 k instances: 6.1 vs 6.9 us).
+template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder>
+__global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
+  static_assert(kOrder == 1 || kOrder == 3, "unknown order");
+  static_assert(kGeneral || !kBoxOverride, "a box override may be non-finite");
+  __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];    // rows 0..2 of every matrix
+  __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3 + mesh id
+  // the tile's commands, in order: order 1 reuses the staging area of waves 1-3 once they have stored;
+  // order 3 has an area of its own (which holds the mesh-table cache before that)
+  __shared__ __attribute__((aligned(16))) uint32_t s_cmd_own[kOrder == 3 ? kTile * kCmdLdsWords : 4];
   static_assert((kTile - 64) * 12 >= kTile * kCmdLdsWords, "commands must fit the staging area of waves 1-3");
+  uint32_t* const s_cmd = kOrder == 1 ? reinterpret_cast<uint32_t*>(&s_mat[64 * 12]) : s_cmd_own;
   __shared__ uint32_t s_wave_count[kWaves], s_wave_sum[kWaves];
+  __shared__ unsigned long long s_vis[kWaves];
+  __shared__ unsigned long long s_tile_agg;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool want_cmds = a.cmds != nullptr;
   uint32_t tile = blockIdx.x;
   if constexpr (kTicketedTiles) {
     __shared__ uint32_t s_tile;
@@ -480,6 +550,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
       // the holder of the last ticket knows every other workgroup already has its own: it re-arms
       // the counter for the next launch on this frame slot
       if (s_tile == a.n_tiles - 1u) __hip_atomic_store(a.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_tile_agg = 0ull;
     }
     __syncthreads();
     tile = s_tile;
@@ -495,8 +566,35 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   const float4 q = a.rot[il];
   const float sc = a.scale[il];
   const uint32_t mesh = a.mesh_id[il];
-  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
-  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  // Small mesh tables are staged in LDS (inside the command area, which is not written before every
+  // wave has finished its arithmetic): the box then costs an LDS read after the mesh id arrives
+  // instead of a second, dependent trip through the vector memory queue.
+#ifdef MIP_EXP_MESH_CACHE  // measured: no gain at 100 k / 1 M / 10 M (the gather is not what the publish waits for)
+  const bool mesh_cached = kOrder == 3 && want_cmds && a.n_meshes <= kMeshCacheEntries;
+#else
+  const bool mesh_cached = false;
+#endif
+  static_assert(kMeshCacheEntries * 32u <= kTile * kCmdLdsWords * 4u, "the mesh cache lives inside the command area");
+  if (mesh_cached && tid < 2u * a.n_meshes)
+    reinterpret_cast<float4*>(s_cmd)[tid] = reinterpret_cast<const float4*>(a.meshes)[tid];
+  if constexpr (!kTicketedTiles) {
+    // the LDS word the waves add their aggregates to; the barrier does not wait for the instance
+    // loads above, and every wave of the workgroup has only just started
+    if (want_cmds) {
+      if (tid == 0) s_tile_agg = 0ull;
+      __syncthreads();
+    }
+  } else {
+    if (mesh_cached) __syncthreads();
+  }
+  float4 mb0, mb1;
+  if (mesh_cached) {
+    mb0 = reinterpret_cast<const float4*>(s_cmd)[2u * mesh];
+    mb1 = reinterpret_cast<const float4*>(s_cmd)[2u * mesh + 1u];
+  } else {
+    mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
+    mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  }
   MeshEntry mb;
   mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
   mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
@@ -504,25 +602,23 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   // ---- model matrix + world AABB ----
   float r[3][3];
   quat_to_rotation(q.x, q.y, q.z, q.w, r);
-  // Finite test for the fast path: a sum of magnitudes is NaN/inf as soon as one term is
-  // (or the sum overflows — then the general path, which is exact for everything, runs).
-  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
-#pragma unroll
-  for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
-  if constexpr (kBoxOverride) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
-    const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;  // {min xyz, -}, {max xyz, -}
-    const float4 lo = b4[0], hi = b4[1];
-    mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
-    mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
-    // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
-    mag += fabsf(lo.x) + fabsf(lo.y) + fabsf(lo.z) + fabsf(hi.x) + fabsf(hi.y) + fabsf(hi.z);
-  }
-  const bool all_finite = mag < 3.0e38f;
   Instance inst;
-  if (__builtin_expect(__any(!all_finite), 0)) {
-    instance_general(r, px, py, pz, sc, mb, inst);
+  if constexpr (kGeneral) {
+    float mag = finite_magnitude(r, px, py, pz, sc);
+    if constexpr (kBoxOverride) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
+      const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;  // {min xyz, -}, {max xyz, -}
+      const float4 lo = b4[0], hi = b4[1];
+      mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
+      mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
+      // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
+      mag += fabsf(lo.x) + fabsf(lo.y) + fabsf(lo.z) + fabsf(hi.x) + fabsf(hi.y) + fabsf(hi.z);
+    }
+    const bool all_finite = mag < kFiniteLimit;
+    if (__builtin_expect(__any(!all_finite), 0)) {
+      instance_general(r, px, py, pz, sc, mb, inst);
+    } else {
+      instance_fast(r, px, py, pz, sc, mb, inst);
+    }
   } else {
     instance_fast(r, px, py, pz, sc, mb, inst);
   }
@@ -533,21 +629,36 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   const bool visible = active && !culled;
   const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
   const float dist_sq = dx * dx + dy * dy + dz * dz;
-  const uint32_t len = (dist_sq > kLodDistSqThreshold) ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
+  const bool far_lod = dist_sq > kLodDistSqThreshold;
+  const uint32_t len = far_lod ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
   const bool keep = visible && len > 0u;  // compact_draw_stream.comp:41 `indexCount > 0`
   const uint32_t len_vis = visible ? len : 0u;
 
-  // ---- wave-level compaction offsets ----
+  // ---- wave-level compaction offsets; the last wave to get here publishes the tile's aggregate ----
   const unsigned long long keep_mask = __ballot(keep);
   const unsigned long long vis_mask = __ballot(visible);
   const uint32_t rank_in_wave = lanes_below(keep_mask);
   const uint32_t incl_sum = wave_inclusive_scan(len_vis);
-  if (lane == 63u) {
-    s_wave_count[wave] = (uint32_t)__popcll(keep_mask);
+#ifdef MIP_DEBUG_STAMPS
+  // fault injection (diagnostic build only): one tile never publishes, so every later tile's
+  // bounded wait must expire and the launch must end with MIP_ERR_TIMEOUT instead of hanging
+  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
+#else
+  const bool skip_publish = false;
+#endif
+  if (want_cmds && lane == 63u) {
+    const uint32_t wc = (uint32_t)__popcll(keep_mask);
+    s_wave_count[wave] = wc;
     s_wave_sum[wave] = incl_sum;
+    const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | wc;
+    const unsigned long long all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
+    // Published before any bulk store of this wave and without waiting for a barrier: the
+    // successors' look-ups depend on it, nothing else does.
+    if (((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish)
+      publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
   }
 
-  // ---- stage the matrix rows for the transposed store ----
+  // ---- stage the matrix rows for the transposed store (three conflict-free ds_write_b128, 48-B pitch) ----
   if (a.model || a.tlas_instances) {
     float4* dst = reinterpret_cast<float4*>(&s_mat[tid * 12]);
     dst[0] = make_float4(inst.m[0], inst.m[1], inst.m[2], inst.m[3]);
@@ -555,8 +666,126 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
     dst[2] = make_float4(inst.m[8], inst.m[9], inst.m[10], inst.m[11]);
     s_row3[tid] = inst.row3 | (mesh << 4);  // NaN bits of row 3 + the mesh id (for the TLAS rows)
   }
-  __syncthreads();
+  if (lane == 0u) s_vis[wave] = vis_mask;
 
+  // One 1-KiB piece = 16 staged matrices -> one store instruction of a wave (64 B per matrix,
+  // lane-contiguous 16-B stores). Piece p of the tile covers instances tile_first + 16 p ...
+  auto store_piece = [&](uint32_t p) {
+    const uint32_t local = 16u * p + (lane >> 2);  // matrix within the tile
+    const uint32_t col = lane & 3u;
+    const float* src = &s_mat[local * 12u];
+    const bool in_range = tile_first + local < a.n;
+    if (a.model) {
+      float w = (col == 3u) ? 1.0f : 0.0f;
+      if constexpr (kGeneral) {
+        const uint32_t bits = s_row3[local] & 15u;
+        if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
+      }
+      if (in_range)
+        store_stream16(&a.model[(size_t)tile_first * 4 + 64u * p + lane], make_float4(src[3u * col], src[3u * col + 1u], src[3u * col + 2u], w));
+    }
+    // optional TLAS instance rows (acceleration_strucures.rs:419-451), same transposed store:
+    // VkAccelerationStructureInstanceKHR = { 3x4 row-major transform = rows 0..2 of M,
+    //   instanceCustomIndex:24 = draw_index | mask:8 = 0xFF, sbtOffset:24 = 0 | flags:8 =
+    //   TRIANGLE_FACING_CULL_DISABLE, BLAS device address }, for EVERY instance (visible or not).
+    if (a.tlas_instances) {
+      const uint32_t draw = tile_first + local;
+      uint4 v;
+      if (col < 3u) {  // row `col`: one element of each staged column
+        v = make_uint4(__float_as_uint(src[col]), __float_as_uint(src[col + 3u]), __float_as_uint(src[col + 6u]), __float_as_uint(src[col + 9u]));
+      } else {
+        const uint32_t mesh_of = s_row3[local] >> 4;
+        const unsigned long long blas = (in_range && a.blas_address) ? a.blas_address[mesh_of] : 0ull;
+        v = make_uint4(((a.first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
+                       (uint32_t)blas, (uint32_t)(blas >> 32));
+      }
+      if (in_range)
+        store_stream16(reinterpret_cast<float4*>(&a.tlas_instances[(size_t)tile_first * 4 + 64u * p + lane]),
+                       make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+    }
+  };
+  // optional world AABB (mins, maxs) as the ECS component holds it: 24 B per lane
+  auto store_aabb = [&]() {
+    if (a.world_aabb && active) {
+      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
+      o2[0] = make_float2(inst.mins[0], inst.mins[1]);
+      o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
+      o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
+    }
+  };
+  // visibility bitmap: the tile's eight words, one store instruction
+  auto store_bitmap = [&]() {
+    if (a.bitmap && lane < 2u * kWaves) {
+      const uint32_t word = (tile_first >> 5) + lane;
+      if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(s_vis[lane >> 1] >> (32u * (lane & 1u)));
+    }
+  };
+
+  if constexpr (kOrder == 1) {
+    auto own_stores = [&]() {
+#pragma unroll
+      for (uint32_t p = 0; p < 4; ++p) store_piece(wave * 4u + p);
+      if (a.bitmap && lane < 2u) {
+        const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
+        if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
+      }
+      store_aabb();
+    };
+    __syncthreads();
+    if (!want_cmds) { own_stores(); return; }
+    uint32_t wave_off_count = 0, wave_off_sum = 0, tile_count = 0, tile_sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; ++w) {
+      const uint32_t wc = s_wave_count[w], ws = s_wave_sum[w];
+      if (w < wave) { wave_off_count += wc; wave_off_sum += ws; }
+      tile_count += wc;
+      tile_sum += ws;
+    }
+    MIP_STAMP(2);
+    if (wave != 0) own_stores();
+    __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
+    if (keep) {
+      const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
+      uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
+      c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = a.first_instance_base + i;
+      c[5] = far_lod ? md.z : md.y;
+    }
+    __syncthreads();
+    MIP_STAMP(3);
+    if (wave != 0) return;
+    uint32_t base_count = 0, base_sum = 0;
+    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+    if (lane == 0 && tile == a.n_tiles - 1u) {
+      *a.draw_count = base_count + tile_count;
+      if (a.index_total) *a.index_total = base_sum + tile_sum;
+    }
+    MIP_STAMP(4);
+    const uint32_t first_index_add = base_sum + a.first_index_base;
+    uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
+    const uint32_t words = tile_count * kCmdWords;
+    for (uint32_t j = lane; j < words; j += 64u) {
+      const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
+      uint32_t v = s_cmd[k * kCmdLdsWords + f];
+      if (f == 2u) v += first_index_add;
+      out[j] = v;
+    }
+    if (a.src_index_offset)
+      for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
+    own_stores();
+    MIP_STAMP(5);
+    return;
+  }
+  if (!want_cmds) {  // no compaction: every wave stores its own quarter of the tile
+    __syncthreads();
+#pragma unroll
+    for (uint32_t p = 0; p < 4; ++p) store_piece(wave * 4u + p);
+    if (wave == 0) store_bitmap();
+    store_aabb();
+    return;
+  }
+
+  __syncthreads();  // the four wave aggregates are in LDS
+  MIP_STAMP(2);
   uint32_t wave_off_count = 0, wave_off_sum = 0, tile_count = 0, tile_sum = 0;
 #pragma unroll
   for (uint32_t w = 0; w < kWaves; ++w) {
@@ -566,93 +795,8 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
     tile_sum += ws;
   }
 
-  const bool want_cmds = a.cmds != nullptr;
-#ifdef MIP_DEBUG_STAMPS
-  // fault injection (diagnostic build only): one tile never publishes, so every later tile's
-  // bounded wait must expire and the launch must end with MIP_ERR_TIMEOUT instead of hanging
-  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
-#else
-  const bool skip_publish = false;
-#endif
-  if (want_cmds && tid == 0 && !skip_publish) publish_aggregate(a, tile, tile_count, tile_sum);
-  MIP_STAMP(2);
-
-  // Bulk stores of this wave: matrices, visibility words, optional AABBs. Wave 0 issues
-  // them only AFTER it has resolved the tile prefix: loads return in order with stores
-  // (vmcnt counts both), so a poll behind 4 KiB of stores would wait for their acks.
-  auto bulk_stores = [&]() {
-    // ---- model matrices: 4 store instructions per wave, each 1 KiB contiguous ----
-    if (a.model) {
-      const uint32_t wave_first = wave * 64u;
-      const float* src = &s_mat[wave_first * 12];
-      float4* out = a.model + ((size_t)tile_first + wave_first) * 4;
-      const uint32_t col = lane & 3u;
-  #pragma unroll
-      for (uint32_t s4 = 0; s4 < 4; ++s4) {
-        const uint32_t local = 16u * s4 + (lane >> 2);  // matrix within the wave
-        const uint32_t flat = 192u * s4 + 3u * lane;    // = local*12 + col*3
-        const uint32_t bits = s_row3[wave_first + local] & 15u;
-        float w = (col == 3u) ? 1.0f : 0.0f;
-        if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
-        if (tile_first + wave_first + local < a.n)
-          out[64u * s4 + lane] = make_float4(src[flat], src[flat + 1], src[flat + 2], w);
-      }
-    }
-
-    // ---- optional TLAS instance rows (acceleration_strucures.rs:419-451), same transposed store ----
-    // VkAccelerationStructureInstanceKHR = { 3x4 row-major transform = rows 0..2 of M,
-    //   instanceCustomIndex:24 = draw_index | mask:8 = 0xFF, sbtOffset:24 = 0 | flags:8 =
-    //   TRIANGLE_FACING_CULL_DISABLE, BLAS device address }, for EVERY instance (visible or not).
-    if (a.tlas_instances) {
-      const uint32_t wave_first = wave * 64u;
-      const float* src = &s_mat[wave_first * 12];
-      uint4* out = a.tlas_instances + ((size_t)tile_first + wave_first) * 4;
-      const uint32_t q = lane & 3u;
-  #pragma unroll
-      for (uint32_t s4 = 0; s4 < 4; ++s4) {
-        const uint32_t local = 16u * s4 + (lane >> 2);
-        const uint32_t draw = tile_first + wave_first + local;
-        uint4 v;
-        if (q < 3u) {  // row q: one element of each staged column
-          const float* col = src + local * 12u + q;
-          v = make_uint4(__float_as_uint(col[0]), __float_as_uint(col[3]), __float_as_uint(col[6]), __float_as_uint(col[9]));
-        } else {
-          const uint32_t mesh_of = s_row3[wave_first + local] >> 4;
-          const unsigned long long blas = (draw < a.n && a.blas_address) ? a.blas_address[mesh_of] : 0ull;
-          v = make_uint4(((a.first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
-                         (uint32_t)blas, (uint32_t)(blas >> 32));
-        }
-        if (draw < a.n) out[64u * s4 + lane] = v;
-      }
-    }
-
-    // ---- visibility bitmap: one 64-bit ballot per wave, written as two words ----
-    if (a.bitmap && lane < 2u) {
-      const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
-      if (word < a.bitmap_words) a.bitmap[word] = (uint32_t)(vis_mask >> (32u * lane));
-    }
-
-    // ---- optional world AABB (mins, maxs) as the ECS component holds it ----
-    if (a.world_aabb && active) {
-      float2* o2 = reinterpret_cast<float2*>(a.world_aabb + (size_t)i * 6);
-      o2[0] = make_float2(inst.mins[0], inst.mins[1]);
-      o2[1] = make_float2(inst.mins[2], inst.maxs[0]);
-      o2[2] = make_float2(inst.maxs[1], inst.maxs[2]);
-    }
-
-  };
-
-  if (!want_cmds) {
-    bulk_stores();
-    return;
-  }
-
-  if (wave != 0) bulk_stores();
-  __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
-
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
-    const bool far_lod = dist_sq > kLodDistSqThreshold;
     const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
     uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
     c[0] = len;                                               // indexCount
@@ -662,16 +806,33 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
     c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
     c[5] = far_lod ? md.z : md.y;                             // push constant indexOffset, cull_pipeline.rs:552
   }
-  __syncthreads();  // s_cmd complete
+  __syncthreads();  // commands, staged matrices and visibility words of every wave are in LDS
   MIP_STAMP(3);
 
-  // Waves 1-3 are finished: they exit and free their registers and wave slots for the next
-  // workgroup while wave 0 alone waits for the tile's prefix and copies the commands out.
-  if (wave != 0) return;
+  // Waves 1-3 put the tile's bulk bytes on their way — all sixteen matrix pieces, wave 0's
+  // included — and exit; their store instructions stall for microseconds once the chip's write
+  // path is saturated. Wave 0 issues no bulk store: it spends that time on the one memory round trip
+  // of the tile's prefix and then copies the commands out.
+  if (wave != 0) {
+#ifdef MIP_EXP_STRIDED_PIECES
+    for (uint32_t p = wave - 1u; p < 16u; p += kWaves - 1u) store_piece(p);
+#else
+    // contiguous runs (6 + 5 + 5 KiB): consecutive store instructions of a wave stay in one DRAM page
+    const uint32_t p0 = wave == 1u ? 0u : (wave == 2u ? 6u : 11u), p1 = wave == 1u ? 6u : (wave == 2u ? 11u : 16u);
+    for (uint32_t p = p0; p < p1; ++p) store_piece(p);
+#endif
+    if (wave == 1) store_bitmap();
+    store_aabb();
+    return;
+  }
 
-  // ---- exclusive prefix over the earlier tiles, before any bulk store of this wave ----
+  // ---- exclusive prefix over the earlier tiles ----
   uint32_t base_count = 0, base_sum = 0;
+#ifndef MIP_EXP_NO_HOP  // tuning builds only: what the kernel costs without the cross-tile look-up (results are wrong)
   if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+#else
+  base_count = tile * 64u;
+#endif
   if (lane == 0 && tile == a.n_tiles - 1u) {
     *a.draw_count = base_count + tile_count;
     if (a.index_total) *a.index_total = base_sum + tile_sum;
@@ -690,7 +851,7 @@ __global__ __launch_bounds__(kTile, MIP_MIN_WAVES_PER_SIMD) void mip_instance_pi
   }
   if (a.src_index_offset)
     for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
-  bulk_stores();
+  store_aabb();
   MIP_STAMP(5);
 }
 

@@ -30,6 +30,8 @@ struct MipContext {
   uint32_t n = 0, m = 0;
   bool have_instances = false, have_meshes = false;
   bool ordered_tiles = false;  // MIP_CFG_ORDERED_TILES, or set by the first MIP_ERR_TIMEOUT
+  int force_order = 0;         // tuning (MIP_TUNE_ORDER): 1 or 3, 0 = by instance count
+  bool force_general = false;  // tuning/tests (MIP_TUNE_FORCE_GENERAL): always launch the kernel with the literal cold path
   // One slot per frame in flight: its own stream and its own cross-tile prefix state, so that
   // consecutive frames may overlap on the device (MipConfig.frames_in_flight).
   struct FrameSlot {
@@ -96,6 +98,10 @@ struct MipContext {
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
+  // upload-time census of instances that fail the kernel's finite test (instance_kernel.hpp,
+  // finite_magnitude): while it is zero, frames run the kernel without the literal cold path
+  uint64_t nonfinite_instances = 0;
+  uint32_t* d_census = nullptr;
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
   // staging for MIP_OUT_HOST
@@ -212,6 +218,48 @@ const RcclApi* rccl() {
   return api.handle ? &api : nullptr;
 }
 
+// Which instantiation of the frame kernel a launch uses: the one without the literal cold path
+// whenever the census says every resident instance passes the finite test (and no per-instance
+// box override, which may be non-finite, is in play).
+using FrameKernel = void (*)(const mip::KernelArgs);
+template <bool kBox, bool kGeneral>
+FrameKernel pick_order(bool ticketed, int order) {
+  if (ticketed)
+    return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1>
+                      : (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 3>;
+  return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1>
+                    : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 3>;
+}
+FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override) {
+  // order (instance_kernel.hpp): commands-first while the launch is less than two generations of
+  // workgroups (8 per CU: every tile is ramp or tail), stores-first once there is a steady state.
+  // Measured cross-over on MI355X: equal at 0.7-1 M instances, order 3 ahead below (200 k: 7.7 vs
+  // 8.4 us), order 1 ahead above (1.25 M: 24.3 vs 25.3 us; 10 M: 191 vs 240 us).
+  int order = tiles_for(ctx->n) <= (uint32_t)ctx->cu_count * 16u ? 3 : 1;
+  if (ctx->force_order) order = ctx->force_order;
+  if (box_override) return pick_order<true, true>(ctx->ordered_tiles, order);
+  if (ctx->nonfinite_instances != 0 || ctx->force_general) return pick_order<false, true>(ctx->ordered_tiles, order);
+  return pick_order<false, false>(ctx->ordered_tiles, order);
+}
+
+// Number of instances of [first, first + count) of the resident columns that fail the finite test.
+// Synchronous (uploads are): one small kernel and a 4-byte read-back on the upload stream.
+int32_t census(MipContext* ctx, uint32_t first, uint32_t count, uint32_t* out) {
+  *out = 0;
+  if (!count) return MIP_OK;
+  MIP_HIP(ctx, hipMemsetAsync(ctx->d_census, 0, 4, ctx->stream));
+  mip::CensusArgs c{};
+  c.pos = ctx->d_pos; c.rot = ctx->d_rot; c.scale = ctx->d_scale;
+  c.first = first; c.count = count; c.out = ctx->d_census;
+  uint32_t blocks = (count + 255u) / 256u;
+  if (blocks > 2048u) blocks = 2048u;
+  hipLaunchKernelGGL(mip::mip_count_nonfinite_kernel, dim3(blocks), dim3(256), 0, ctx->stream, c);
+  MIP_HIP(ctx, hipGetLastError());
+  MIP_HIP(ctx, hipMemcpyAsync(out, ctx->d_census, 4, hipMemcpyDeviceToHost, ctx->stream));
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MIP_OK;
+}
+
 // Everything of a launch except the tag: resident inputs, output pointers, prefix state, frame.
 void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame* frame, const MipOutputs* out,
                       bool device_out, mip::KernelArgs& a) {
@@ -236,6 +284,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.error_flag = ctx->d_error;
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
+  a.n_meshes = ctx->m;
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
@@ -298,6 +347,7 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_scale);
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
+  (void)hipFree(ctx->d_census);
   if (ctx->comm && rccl()) (void)rccl()->comm_destroy(ctx->comm);
   (void)hipFree(ctx->d_send);
   (void)hipFree(ctx->d_recv);
@@ -377,6 +427,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_id, cap * 4));
     MIP_HIP(ctx, hipMalloc(&ctx->d_meshes, mcap * sizeof(mip::MeshEntry)));
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_draw, mcap * sizeof(mip::MeshDraw)));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_census, 4));
     ctx->cu_count = prop.multiProcessorCount;
     const size_t tiles_cap = tiles_for((uint32_t)cap);
     // smallest group the kernel may pick is 16 tiles (group_shift 4)
@@ -404,6 +455,11 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDERED_TILES")) ctx->ordered_tiles = std::atoi(env) != 0;
+    if (const char* env = std::getenv("MIP_TUNE_ORDER")) {
+      const int v = std::atoi(env);
+      if (v == 1 || v == 3) ctx->force_order = v;
+    }
+    if (const char* env = std::getenv("MIP_TUNE_FORCE_GENERAL")) ctx->force_general = std::atoi(env) != 0;
     if (const char* env = std::getenv("MIP_TUNE_GRAPH_ROUND")) ctx->graph_round = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TEST_EPOCH_START"))  // tests: start next to the tag wrap
       for (auto& sl : ctx->slots) sl.epoch = (uint32_t)std::strtoul(env, nullptr, 10);
@@ -512,6 +568,10 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind, ctx->stream));
     MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // stream-ordered copies: finished before any slot launches again
   }
+  uint32_t bad = 0;
+  if (int32_t rc = census(ctx, 0, n, &bad)) return rc;
+  if ((bad != 0) != (ctx->nonfinite_instances != 0)) ctx->graph_generation++;  // recorded launches name the other kernel
+  ctx->nonfinite_instances = bad;
   if (n != ctx->n) {
     for (auto& sl : ctx->slots) sl.status_dirty = true;  // tile/group geometry changes with n
     for (auto& sl : ctx->view_states) sl.status_dirty = true;
@@ -545,11 +605,17 @@ int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, co
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   if (count) {
+    uint32_t bad_before = 0, bad_after = 0;
+    if (int32_t rc = census(ctx, first, count, &bad_before)) return rc;
     if (pos_xyz) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_pos + (size_t)first * 3, pos_xyz, (size_t)count * 12, hipMemcpyHostToDevice, ctx->stream));
     if (rot_ijkw) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_rot + first, rot_ijkw, (size_t)count * 16, hipMemcpyHostToDevice, ctx->stream));
     if (scale) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_scale + first, scale, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     if (mesh_id) MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_id + first, mesh_id, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int32_t rc = census(ctx, first, count, &bad_after)) return rc;
+    const uint64_t total = ctx->nonfinite_instances - bad_before + bad_after;
+    if ((total != 0) != (ctx->nonfinite_instances != 0)) ctx->graph_generation++;
+    ctx->nonfinite_instances = total;
   }
   return MIP_OK;
 }
@@ -634,16 +700,10 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       MIP_HIP(ctx, hipGetLastError());
     }
     {
-      const dim3 grid(a.n_tiles), block(mip::kTile);
-      if (skinned) {
-        if (ctx->ordered_tiles) hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<true, true>), grid, block, ctx->lds_pad, stream, a);
-        else hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<false, true>), grid, block, ctx->lds_pad, stream, a);
-      } else {
-        if (ctx->ordered_tiles) hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<true, false>), grid, block, ctx->lds_pad, stream, a);
-        else hipLaunchKernelGGL((mip::mip_instance_pipeline_kernel<false, false>), grid, block, ctx->lds_pad, stream, a);
-      }
+      void* params[1] = {&a};
+      MIP_HIP(ctx, hipLaunchKernel((const void*)select_frame_kernel(ctx, skinned), dim3(a.n_tiles), dim3(mip::kTile), params,
+                                   ctx->lds_pad, stream));
     }
-    MIP_HIP(ctx, hipGetLastError());
     if (triangles) {
       mip::TriangleArgs t{};
       t.cmds = sl.d_tmp_cmds;
@@ -808,7 +868,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const Mi
         a.epoch = base + 1 + j;
         void* params[1] = {&a};
         hipKernelNodeParams kp{};
-        kp.func = ctx->ordered_tiles ? (void*)mip::mip_instance_pipeline_kernel<true, false> : (void*)mip::mip_instance_pipeline_kernel<false, false>;
+        kp.func = (void*)select_frame_kernel(ctx, false);
         kp.gridDim = dim3(a.n_tiles);
         kp.blockDim = dim3(mip::kTile);
         kp.sharedMemBytes = ctx->lds_pad;

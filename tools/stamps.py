@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from renderer_amd import _lib
 
-_lib._SO = os.path.join(ROOT, "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
+_lib._SO = os.environ.get("MIP_STAMPS_LIB") or os.path.join(ROOT, "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
 import renderer_amd
 from renderer_amd import scene
 from renderer_amd.pipeline import make_frame
