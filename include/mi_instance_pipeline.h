@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIP_ABI_VERSION 1u
+#define MIP_ABI_VERSION 2u
 
 /* ---- status codes (0 = success, negative = error; like VkResult in vma) ---- */
 #define MIP_OK 0
@@ -167,6 +167,9 @@ typedef struct MipTimings {
   uint64_t merges;
   uint64_t graph_frames;      /* frames mip_run_many replayed from recorded launch graphs (counted even without MIP_CFG_TIMING) */
   uint64_t graph_records;     /* times it had to record a new set of graphs */
+  uint64_t sharded_retries;   /* sharded frames whose tightened chunk overflowed and were re-gathered at full capacity */
+  uint64_t general_launches;  /* frames launched with the kernel that carries the literal path for non-finite
+                                 inputs (some resident instance failed the upload-time finite test, or a skinned frame) */
 } MipTimings;
 
 /* Chunk header used by mip_merge_draw_lists: what each rank contributes to the
@@ -230,16 +233,21 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
  * MIP_OUT_ASYNC. */
 int32_t mip_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out);
 
-/* Enqueue `steps` frames back to back from compiled code: frame k uses outputs[k % n_outputs]
- * (give at least frames_in_flight output sets). Every output set must carry
- * MIP_OUT_DEVICE | MIP_OUT_ASYNC. Equivalent to calling mip_run `steps` times; exists so that a
- * host in a scripting language does not pay its per-call overhead per frame, and so that the
- * launches can be recorded once and replayed: when every output set asks for draw commands
- * and none for the per-triangle stage, whole rounds of ~64 frames go out as one hipGraph
- * per frame slot (recorded on first use, cached by frame/outputs; MipTimings.graph_frames
- * counts them); the remainder and every other case are plain mip_run calls. */
-int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
-                     uint32_t steps);
+/* Enqueue `steps` frames back to back from compiled code — the renderer's 'frame: loop
+ * (src/main.rs:907-926), in which project_camera (src/ecs.rs:66-91) produces new planes every frame:
+ * step k runs frames[k % n_frames] into outputs[k % n_outputs] (give at least frames_in_flight
+ * output sets). Every output set must carry MIP_OUT_DEVICE | MIP_OUT_ASYNC. Equivalent to calling
+ * mip_run `steps` times; exists so that a host in a scripting language does not pay its per-call
+ * overhead per frame, and so that the launches can be recorded once and replayed: when every
+ * output set asks for draw commands and none for the per-triangle stage, whole rounds of ~64 frames
+ * go out as one hipGraph per frame slot. The graphs are recorded on first use and cached by the
+ * OUTPUT sets only — a frame's planes, camera position and bases are not baked into them (each
+ * recorded launch reads its frame from a small device-side ring that one copy refreshes per
+ * replay), so a moving camera replays the same graphs (MipTimings.graph_records stays put,
+ * graph_frames counts the replayed frames); the remainder and every other case are plain mip_run
+ * calls. */
+int32_t mip_run_many(MipContext* ctx, const MipFrame* frames, uint32_t n_frames, const MipOutputs* outputs,
+                     uint32_t n_outputs, uint32_t steps);
 
 /* Row f-4, second consumer — the shadow pass's per-light draw lists
  * (src/renderer/systems/shadow_mapping.rs:405-478: for every light, for every mesh entity,
@@ -312,11 +320,14 @@ int32_t mip_wait(MipContext* ctx);
  * out_count[1] = total indices (so out_count needs room for 2 words). DEVICE pointers. Enqueued on the
  * context's first stream (MipConfig.stream, or frame slot 0's): it is ordered after a frame of the same
  * context only when frames_in_flight == 1 — use one context per frame in flight for sharded frames, as
- * mip_run_sharded and renderer_amd/sharded.py do. Synchronous unless `async` is non-zero. `out_cmds`
- * needs room for the sum of the counts. */
+ * mip_run_sharded and renderer_amd/sharded.py do. Synchronous unless `async` is non-zero.
+ * `chunk_capacity` = commands one chunk may carry (0 = what the stride holds): `out_cmds` needs room for
+ * n_chunks x chunk_capacity commands, and a chunk whose header count exceeds it is cut there and
+ * reported (MIP_ERR_CAPACITY from this call, or from mip_wait for an async one) — the stride is
+ * usually rounded up and may physically hold a few commands more than the capacity. */
 int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks,
-                             uint64_t chunk_stride_bytes, void* out_cmds, uint32_t* out_count,
-                             int32_t async);
+                             uint64_t chunk_stride_bytes, uint32_t chunk_capacity, void* out_cmds,
+                             uint32_t* out_count, int32_t async);
 
 /* ---- sharded scenes without a Python host: RCCL straight from the library ------------------
  * librccl.so.1 is opened with dlopen on first use, so single-GPU hosts do not need it. The
@@ -338,13 +349,38 @@ typedef struct MipShardedOutputs {
   void* draw_cmds;          /* the MERGED global list; room for world x chunk_capacity commands */
   uint32_t* draw_count;     /* [0] merged command count, [1] merged index total */
   uint32_t chunk_capacity;  /* commands each rank contributes at most; 0 = the context's max_instances.
-                               A rank that emits more raises MIP_ERR_CAPACITY (never cut silently) */
+                               If ANY rank emits more, every rank sees it in the gathered headers and the
+                               library repeats the all-gather + merge of that frame once at full capacity
+                               (at once for a synchronous call, inside mip_wait for an asynchronous one;
+                               MipTimings.sharded_retries counts them): draw_cmds therefore needs room for
+                               world x max_instances commands whenever chunk_capacity is tightened */
   uint32_t flags;           /* MIP_OUT_DEVICE, optionally | MIP_OUT_ASYNC */
 } MipShardedOutputs;
 
 /* One frame of a sharded scene on this rank (collective: every rank calls it with the same
- * chunk_capacity). frame->first_instance_base must be the shard's first draw_index. */
+ * chunk_capacity). frame->first_instance_base must be the shard's first draw_index. With
+ * MIP_OUT_ASYNC and a tightened chunk_capacity call mip_wait before the next sharded frame: the
+ * repair of an overflowing frame re-sends this rank's list, which the next frame overwrites
+ * (an overflow that can no longer be repaired is reported as MIP_ERR_CAPACITY). */
 int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipShardedOutputs* out);
+
+/* ---- zero-copy interop with the renderer's own allocations ----------------
+ * The reference keeps the buffers this path fills in VMA allocations of its Vulkan device:
+ * ModelData.model_buffer (src/renderer.rs:1225-1265), IndirectCommandsBuffer / IndirectCommandsCount
+ * (src/renderer/systems/cull_pipeline.rs:70-72,183-220), declared GPU_ONLY by the buffer macro
+ * (src/renderer/macros/macros.rs:67-79) on an allocator created without exportable handle types
+ * (src/renderer/device/alloc.rs:154-171). Once such a buffer is allocated from a memory block created
+ * with VkExportMemoryAllocateInfo{handleTypes = VK_EXTERNAL_MEMORY_HANDLE_TYPE_OPAQUE_FD_BIT} (on amdgpu
+ * the fd is a dma-buf; INTEGRATION.md §3 lists the VMA / Vulkan flags) and exported with
+ * vkGetMemoryFdKHR, this call maps the same bytes into the context's HIP device:
+ * hipImportExternalMemory(OpaqueFd) + hipExternalMemoryGetMappedBuffer. `*out_device_ptr` is then a
+ * valid MIP_OUT_DEVICE output pointer (or mip_set_instances_device input) for `size_bytes` bytes.
+ * As with cudaImportExternalMemory, a successfully imported fd belongs to the driver: do not use or
+ * close it afterwards. Ordering against the Vulkan queue is the caller's (a timeline semaphore,
+ * or vkQueueWaitIdle / mip_wait at the hand-over points). */
+int32_t mip_import_external_fd(MipContext* ctx, int32_t fd, uint64_t size_bytes, void** out_device_ptr);
+/* Unmaps a pointer returned by mip_import_external_fd (after mip_wait); mip_destroy releases the rest. */
+int32_t mip_release_external(MipContext* ctx, void* device_ptr);
 
 const char* mip_last_error(const MipContext* ctx);
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out);

@@ -100,11 +100,12 @@ extern "C" {
                             n_indices: u32) -> i32;
     pub fn mip_set_blas_addresses(ctx: *mut MipContext, addresses: *const u64, m: u32) -> i32;
     pub fn mip_run(ctx: *mut MipContext, frame: *const MipFrame, out: *const MipOutputs) -> i32;
-    pub fn mip_run_many(ctx: *mut MipContext, frame: *const MipFrame, outputs: *const MipOutputs, n_outputs: u32,
-                        steps: u32) -> i32;
+    /// Step k runs frames[k % n_frames] into outputs[k % n_outputs]; recorded launch graphs do not bake the frame.
+    pub fn mip_run_many(ctx: *mut MipContext, frames: *const MipFrame, n_frames: u32, outputs: *const MipOutputs,
+                        n_outputs: u32, steps: u32) -> i32;
     pub fn mip_wait(ctx: *mut MipContext) -> i32;
     pub fn mip_merge_draw_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
-                                out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+                                chunk_capacity: u32, out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
     /// Shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, light-major, into device memory.
     pub fn mip_light_draw_lists(ctx: *mut MipContext, light_pos_xyz: *const f32, n_lights: u32, first_instance_base: u32,
                                 out_cmds: *mut c_void, async_: i32) -> i32;
@@ -119,6 +120,9 @@ extern "C" {
     pub fn mip_comm_init(ctx: *mut MipContext, id: *const u8, rank: u32, world: u32) -> i32;
     pub fn mip_comm_destroy(ctx: *mut MipContext) -> i32;
     pub fn mip_run_sharded(ctx: *mut MipContext, frame: *const MipFrame, out: *const MipShardedOutputs) -> i32;
+    /// Row f-2: map an fd exported with vkGetMemoryFdKHR (OPAQUE_FD; a dma-buf on amdgpu) into the HIP device.
+    pub fn mip_import_external_fd(ctx: *mut MipContext, fd: i32, size_bytes: u64, out_device_ptr: *mut *mut c_void) -> i32;
+    pub fn mip_release_external(ctx: *mut MipContext, device_ptr: *mut c_void) -> i32;
     pub fn mip_last_error(ctx: *const MipContext) -> *const c_char;
     pub fn mip_instance_count(ctx: *const MipContext) -> u32;
 }

@@ -27,7 +27,7 @@ MIP_MAX_LODS = 6
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -98,6 +98,8 @@ class MipTimings(C.Structure):
         ("merges", C.c_uint64),
         ("graph_frames", C.c_uint64),
         ("graph_records", C.c_uint64),
+        ("sharded_retries", C.c_uint64),
+        ("general_launches", C.c_uint64),
     ]
 
 
@@ -147,11 +149,11 @@ def load_library():
     lib.mip_set_geometry.restype = C.c_int32
     lib.mip_run.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.mip_run.restype = C.c_int32
-    lib.mip_run_many.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32]
+    lib.mip_run_many.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
     lib.mip_run_many.restype = C.c_int32
     lib.mip_wait.argtypes = [vp]
     lib.mip_wait.restype = C.c_int32
-    lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, vp, vp, C.c_int32]
+    lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
     lib.mip_merge_draw_lists.restype = C.c_int32
     lib.mip_light_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32]
     lib.mip_light_draw_lists.restype = C.c_int32
@@ -171,6 +173,10 @@ def load_library():
     lib.mip_comm_destroy.restype = C.c_int32
     lib.mip_run_sharded.argtypes = [vp, vp, vp]
     lib.mip_run_sharded.restype = C.c_int32
+    lib.mip_import_external_fd.argtypes = [vp, C.c_int32, C.c_uint64, C.POINTER(vp)]
+    lib.mip_import_external_fd.restype = C.c_int32
+    lib.mip_release_external.argtypes = [vp, vp]
+    lib.mip_release_external.restype = C.c_int32
     lib.mip_last_error.argtypes = [vp]
     lib.mip_last_error.restype = C.c_char_p
     lib.mip_get_timings.argtypes = [vp, C.POINTER(MipTimings)]

@@ -96,15 +96,23 @@ struct KernelArgs {
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
   uint32_t n_meshes;            // mesh-table entries (tables of <= kMeshCacheEntries are staged in LDS)
+  // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
+  // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
+  // without re-recording: the host refreshes the ring with one copy per replay
   uint32_t first_instance_base;
   uint32_t first_index_base;
   float planes[24];
   float cam[3];
+  const uint32_t* frame_ring;   // this launch's FrameWords, or null
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
   uint32_t debug_skip_publish_tile;  // diagnostic build only: tile index + 1 that never publishes (0 = off)
 #endif
 };
+
+// Device-side image of a frame for recorded launches: 32 words (128 B).
+//   [0..23] planes, [24..26] cam_pos, [27] first_instance_base, [28] first_index_base, [29..31] pad
+constexpr uint32_t kFrameWords = 32;
 
 #ifdef MIP_DEBUG_STAMPS
 #define MIP_STAMP(k)                                                                       \
@@ -561,6 +569,27 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
   MIP_STAMP(0);
 
+  // ---- the frame: kernel arguments, or (recorded launches) 128 B of device memory read by the
+  //      first 32 lanes of every wave and broadcast, in flight together with the instance loads ----
+  float planes[24], cam[3];
+  uint32_t first_instance_base, first_index_base;
+  if (a.frame_ring) {
+    const uint32_t word = a.frame_ring[lane & (kFrameWords - 1u)];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) planes[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)word, k));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)word, 24 + k));
+    first_instance_base = (uint32_t)__builtin_amdgcn_readlane((int)word, 27);
+    first_index_base = (uint32_t)__builtin_amdgcn_readlane((int)word, 28);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) planes[k] = a.planes[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam[k] = a.cam[k];
+    first_instance_base = a.first_instance_base;
+    first_index_base = a.first_index_base;
+  }
+
   // ---- loads: 36 B per instance ----
   const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
   const float4 q = a.rot[il];
@@ -625,9 +654,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   MIP_STAMP(1);
   // ---- frustum test, LOD, command length ----
-  const bool culled = coarse_culled(inst, a.planes);
+  const bool culled = coarse_culled(inst, planes);
   const bool visible = active && !culled;
-  const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
+  const float dx = cam[0] - px, dy = cam[1] - py, dz = cam[2] - pz;
   const float dist_sq = dx * dx + dy * dy + dz * dz;
   const bool far_lod = dist_sq > kLodDistSqThreshold;
   const uint32_t len = far_lod ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
@@ -696,7 +725,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       } else {
         const uint32_t mesh_of = s_row3[local] >> 4;
         const unsigned long long blas = (in_range && a.blas_address) ? a.blas_address[mesh_of] : 0ull;
-        v = make_uint4(((a.first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
+        v = make_uint4(((first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
                        (uint32_t)blas, (uint32_t)(blas >> 32));
       }
       if (in_range)
@@ -747,7 +776,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     if (keep) {
       const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
       uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
-      c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = a.first_instance_base + i;
+      c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = first_instance_base + i;
       c[5] = far_lod ? md.z : md.y;
     }
     __syncthreads();
@@ -760,7 +789,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       if (a.index_total) *a.index_total = base_sum + tile_sum;
     }
     MIP_STAMP(4);
-    const uint32_t first_index_add = base_sum + a.first_index_base;
+    const uint32_t first_index_add = base_sum + first_index_base;
     uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
     const uint32_t words = tile_count * kCmdWords;
     for (uint32_t j = lane; j < words; j += 64u) {
@@ -803,7 +832,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     c[1] = 1u;                                                // instanceCount, generate_work.comp:63
     c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
     c[3] = md.x;                                              // vertexOffset, :66
-    c[4] = a.first_instance_base + i;                         // firstInstance = draw_index, :64
+    c[4] = first_instance_base + i;                         // firstInstance = draw_index, :64
     c[5] = far_lod ? md.z : md.y;                             // push constant indexOffset, cull_pipeline.rs:552
   }
   __syncthreads();  // commands, staged matrices and visibility words of every wave are in LDS
@@ -840,7 +869,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   MIP_STAMP(4);
 
   // ---- coalesced copy-out of the tile's commands ----
-  const uint32_t first_index_add = base_sum + a.first_index_base;
+  const uint32_t first_index_add = base_sum + first_index_base;
   uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
   const uint32_t words = tile_count * kCmdWords;
   for (uint32_t j = lane; j < words; j += 64u) {

@@ -15,6 +15,7 @@ struct MergeArgs {
   const unsigned char* chunks;
   unsigned long long stride;
   uint32_t n_chunks;
+  uint32_t capacity;    // commands a chunk may carry (what the caller sized out_cmds for: n_chunks x capacity)
   uint32_t* out_cmds;
   uint32_t* out_count;  // [0] = commands, [1] = indices
   uint32_t* error_flag; // host-mapped
@@ -28,7 +29,10 @@ __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeAr
   __shared__ uint32_t s_count_base[kMaxMergeChunks + 1], s_index_base[kMaxMergeChunks + 1];
   if (threadIdx.x == 0) {
     uint32_t c = 0, s = 0;
-    const uint32_t capacity = (uint32_t)((a.stride - 32u) / (kCmdWords * 4u));
+    // never more than the stride physically holds (the stride is rounded up to 256 B, so it may hold
+    // a few commands more than the capacity the caller sized its output for)
+    const uint32_t fits = (uint32_t)((a.stride - 32u) / (kCmdWords * 4u));
+    const uint32_t capacity = a.capacity < fits ? a.capacity : fits;
     for (uint32_t k = 0; k < a.n_chunks; ++k) {
       const uint32_t* h = reinterpret_cast<const uint32_t*>(a.chunks + k * a.stride);
       uint32_t count = h[0];

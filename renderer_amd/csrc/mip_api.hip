@@ -43,6 +43,12 @@ struct MipContext {
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
+    // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
+    // refreshed before every replay from one of two pinned staging halves
+    uint32_t* d_frame_ring = nullptr;
+    uint32_t* h_frame_stage = nullptr;
+    uint32_t frame_ring_frames = 0, stage_next = 0;
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
     uint32_t epoch = 0;         // highest tag handed out on this state
     uint32_t last_tag = 0;      // tag of the last launch (what the level-0 words hold now)
     uint32_t zero_buf = 2;      // which accumulator buffer is all-zero now: 0, 1, or 2 = both
@@ -56,7 +62,6 @@ struct MipContext {
     uint32_t base_epoch = 0;
   };
   struct GraphSet {
-    MipFrame frame{};
     std::vector<MipOutputs> outs;
     uint32_t first_slot = 0, frames_per_slot = 0;
     uint64_t generation = 0;
@@ -118,6 +123,13 @@ struct MipContext {
   uint32_t comm_rank = 0, comm_world = 0;
   uint32_t* d_send = nullptr;  // this rank's chunk, sized for max_instances commands
   uint32_t* d_recv = nullptr;  // world chunks
+  // the last sharded frame, kept so that a tightened chunk that overflowed can be re-gathered at full capacity
+  void* sharded_out_cmds = nullptr;
+  uint32_t* sharded_out_count = nullptr;
+  uint32_t sharded_pending = 0;  // sharded frames enqueued since the last completed wait
+  // imported external memory (mip_import_external_fd)
+  struct External { hipExternalMemory_t mem; void* ptr; };
+  std::vector<External> externals;
   char err[512] = {0};
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* d_stamps = nullptr;
@@ -165,6 +177,8 @@ int32_t ensure_staging(MipContext* ctx, const MipOutputs* out) {
   return MIP_OK;
 }
 
+int32_t repair_sharded_overflow(MipContext* ctx);
+
 // Reads and clears the device-visible error word after the stream has drained.
 int32_t check_device_error(MipContext* ctx) {
   const uint32_t e = *(volatile uint32_t*)ctx->h_error;
@@ -182,8 +196,8 @@ int32_t check_device_error(MipContext* ctx) {
     }
     if (e & mip::kErrIndexOverflow)
       return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
-    return fail(ctx, MIP_ERR_CAPACITY,
-                "a shard's draw list is longer than the exchanged chunk holds; merged list truncated");
+    if (int32_t rc = repair_sharded_overflow(ctx)) return rc;
+    return MIP_OK;
   }
   return MIP_OK;
 }
@@ -342,6 +356,8 @@ void free_all(MipContext* ctx) {
   for (auto& sl : ctx->slots)
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   drop_graphs(ctx);
+  for (auto& e : ctx->externals) (void)hipDestroyExternalMemory(e.mem);  // unmaps the buffer as well
+  ctx->externals.clear();
   (void)hipFree(ctx->d_pos);
   (void)hipFree(ctx->d_rot);
   (void)hipFree(ctx->d_scale);
@@ -365,6 +381,10 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_tmp_src);
     (void)hipFree(sl.d_tmp_blocks);
     (void)hipFree(sl.d_skin_box);
+    (void)hipFree(sl.d_frame_ring);
+    if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
+    for (auto& e : sl.stage_free)
+      if (e) (void)hipEventDestroy(e);
   }
   (void)hipFree(ctx->s_model);
   (void)hipFree(ctx->s_bitmap);
@@ -701,6 +721,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     }
     {
       void* params[1] = {&a};
+      if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
       MIP_HIP(ctx, hipLaunchKernel((const void*)select_frame_kernel(ctx, skinned), dim3(a.n_tiles), dim3(mip::kTile), params,
                                    ctx->lds_pad, stream));
     }
@@ -805,31 +826,65 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
 }
 
 // mip_run_many with the launches recorded once and replayed: per slot a linear hipGraph of
-// G launches of the instance kernel. A launch's only per-frame state is its prefix tag; a chain
-// bakes the tags base+1 .. base+G. Replaying the same tags is sound because every launch rewrites
-// every level-0 word and group start it later reads, so the only stale tag a word can hold is
-// the previous launch's — base+G before the chain's first launch (G >= 2) — and because G is
-// even, so the accumulator buffer the first launch adds into is the one the last launch zeroed.
-static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs,
-                                uint32_t rounds, uint32_t frames_per_slot) {
+// G launches of the instance kernel. Two things change from launch to launch:
+//  - the prefix tag: a chain bakes the tags base+1 .. base+G. Replaying the same tags is sound because
+//    every launch rewrites every level-0 word and group start it later reads, so the only stale tag a
+//    word can hold is the previous launch's — base+G before the chain's first launch (G >= 2) — and
+//    because G is even, so the accumulator buffer the first launch adds into is the one the last
+//    launch zeroed;
+//  - the frame (camera planes, LOD reference point, bases): NOT baked. Node j of a chain reads entry j
+//    of the slot's frame ring in device memory (KernelArgs.frame_ring); the host refreshes the ring
+//    with one stream-ordered copy in front of every replay. A renderer moves its camera every frame
+//    (project_camera runs in the frame loop, src/ecs.rs:66-91, src/main.rs:907-926): the recorded
+//    graphs survive that, and only a change of outputs, instance count or kernel choice re-records.
+static void frame_words(const MipFrame& f, uint32_t* w) {
+  std::memcpy(w, f.planes, 24 * 4);
+  std::memcpy(w + 24, f.cam_pos, 3 * 4);
+  w[27] = f.first_instance_base;
+  w[28] = f.first_index_base;
+  w[29] = w[30] = w[31] = 0;
+}
+
+static void destroy_graph_set(MipContext::GraphSet& gs) {
+  for (auto& fg : gs.per_slot) {
+    if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
+    if (fg.graph) (void)hipGraphDestroy(fg.graph);
+  }
+  gs.per_slot.clear();
+}
+
+static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_t n_frames, uint32_t first_step,
+                                const MipOutputs* outputs, uint32_t n_outputs, uint32_t rounds, uint32_t frames_per_slot) {
   const uint32_t F = (uint32_t)ctx->slots.size();
   const uint32_t G = frames_per_slot;
-  for (auto& sl : ctx->slots)
+  for (auto& sl : ctx->slots) {
     if (int32_t rc = reset_prefix_state_if_needed(ctx, sl, G + 2)) return rc;
+    if (sl.frame_ring_frames < G) {  // ring + two pinned staging halves, sized for one chain
+      MIP_HIP(ctx, hipStreamSynchronize(sl.stream));
+      (void)hipFree(sl.d_frame_ring);
+      if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
+      sl.d_frame_ring = nullptr;
+      sl.h_frame_stage = nullptr;
+      sl.frame_ring_frames = 0;
+      MIP_HIP(ctx, hipMalloc(&sl.d_frame_ring, (size_t)G * mip::kFrameWords * 4));
+      MIP_HIP(ctx, hipHostMalloc(&sl.h_frame_stage, (size_t)2 * G * mip::kFrameWords * 4, hipHostMallocDefault));
+      for (auto& e : sl.stage_free)
+        if (!e) MIP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      sl.frame_ring_frames = G;
+      sl.stage_next = 0;
+      ctx->graph_generation++;  // recorded nodes point into the old ring
+    }
+  }
 
   MipContext::GraphSet* set = nullptr;
   for (size_t i = 0; i < ctx->graph_sets.size();) {
     auto& gs = ctx->graph_sets[i];
-    if (gs.generation != ctx->graph_generation) {  // recorded against another instance count or a cleared state
-      for (auto& fg : gs.per_slot) {
-        if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
-        if (fg.graph) (void)hipGraphDestroy(fg.graph);
-      }
+    if (gs.generation != ctx->graph_generation) {  // recorded against another instance count, kernel or a cleared state
+      destroy_graph_set(gs);
       ctx->graph_sets.erase(ctx->graph_sets.begin() + (long)i);
       continue;
     }
     if (gs.first_slot == ctx->next_slot && gs.frames_per_slot == G && gs.outs.size() == n_outputs &&
-        std::memcmp(&gs.frame, frame, sizeof(MipFrame)) == 0 &&
         std::memcmp(gs.outs.data(), outputs, sizeof(MipOutputs) * n_outputs) == 0)
       set = &gs;
     ++i;
@@ -839,49 +894,56 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const Mi
       if (ctx->slots[(set->first_slot + i) % F].last_tag == set->per_slot[i].base_epoch + 1) set = nullptr;  // cannot happen; re-record if it does
   if (!set) {
     if (ctx->graph_sets.size() >= 4) {
-      for (auto& fg : ctx->graph_sets.front().per_slot) {
-        if (fg.exec) (void)hipGraphExecDestroy(fg.exec);
-        if (fg.graph) (void)hipGraphDestroy(fg.graph);
-      }
+      destroy_graph_set(ctx->graph_sets.front());
       ctx->graph_sets.erase(ctx->graph_sets.begin());
     }
-    ctx->graph_sets.emplace_back();
-    MipContext::GraphSet& gs = ctx->graph_sets.back();
-    gs.frame = *frame;
+    // built aside and moved into the cache only when every slot's chain has instantiated: a failure
+    // half-way must not leave an entry with null graphs that a later call would match and launch
+    MipContext::GraphSet gs;
     gs.outs.assign(outputs, outputs + n_outputs);
     gs.first_slot = ctx->next_slot;
     gs.frames_per_slot = G;
     gs.generation = ctx->graph_generation;
     gs.per_slot.resize(F);
-    for (uint32_t i = 0; i < F; ++i) {
-      MipContext::FrameSlot& sl = ctx->slots[(gs.first_slot + i) % F];
-      MipContext::FrameGraph& fg = gs.per_slot[i];
-      uint32_t base = sl.epoch > sl.last_tag ? sl.epoch : sl.last_tag;
-      if (sl.zero_buf != 2 && ((base + 1) & 1u) != sl.zero_buf) ++base;
-      fg.base_epoch = base;
-      MIP_HIP(ctx, hipGraphCreate(&fg.graph, 0));
-      hipGraphNode_t prev = nullptr;
-      for (uint32_t j = 0; j < G; ++j) {
-        const MipOutputs* out = &outputs[(i + j * F) % n_outputs];
-        mip::KernelArgs a{};
-        fill_kernel_args(ctx, sl, frame, out, true, a);
-        a.epoch = base + 1 + j;
-        void* params[1] = {&a};
-        hipKernelNodeParams kp{};
-        kp.func = (void*)select_frame_kernel(ctx, false);
-        kp.gridDim = dim3(a.n_tiles);
-        kp.blockDim = dim3(mip::kTile);
-        kp.sharedMemBytes = ctx->lds_pad;
-        kp.kernelParams = params;
-        kp.extra = nullptr;
-        hipGraphNode_t node = nullptr;
-        MIP_HIP(ctx, hipGraphAddKernelNode(&node, fg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
-        prev = node;
+    const int32_t rc = [&]() -> int32_t {
+      MipFrame blank{};
+      for (uint32_t i = 0; i < F; ++i) {
+        MipContext::FrameSlot& sl = ctx->slots[(gs.first_slot + i) % F];
+        MipContext::FrameGraph& fg = gs.per_slot[i];
+        uint32_t base = sl.epoch > sl.last_tag ? sl.epoch : sl.last_tag;
+        if (sl.zero_buf != 2 && ((base + 1) & 1u) != sl.zero_buf) ++base;
+        fg.base_epoch = base;
+        MIP_HIP(ctx, hipGraphCreate(&fg.graph, 0));
+        hipGraphNode_t prev = nullptr;
+        for (uint32_t j = 0; j < G; ++j) {
+          const MipOutputs* out = &outputs[(i + j * F) % n_outputs];
+          mip::KernelArgs a{};
+          fill_kernel_args(ctx, sl, &blank, out, true, a);
+          a.frame_ring = sl.d_frame_ring + (size_t)j * mip::kFrameWords;
+          a.epoch = base + 1 + j;
+          void* params[1] = {&a};
+          hipKernelNodeParams kp{};
+          kp.func = (void*)select_frame_kernel(ctx, false);
+          kp.gridDim = dim3(a.n_tiles);
+          kp.blockDim = dim3(mip::kTile);
+          kp.sharedMemBytes = ctx->lds_pad;
+          kp.kernelParams = params;
+          kp.extra = nullptr;
+          hipGraphNode_t node = nullptr;
+          MIP_HIP(ctx, hipGraphAddKernelNode(&node, fg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+          prev = node;
+        }
+        MIP_HIP(ctx, hipGraphInstantiate(&fg.exec, fg.graph, nullptr, nullptr, 0));
       }
-      MIP_HIP(ctx, hipGraphInstantiate(&fg.exec, fg.graph, nullptr, nullptr, 0));
+      return MIP_OK;
+    }();
+    if (rc != MIP_OK) {
+      destroy_graph_set(gs);
+      return rc;
     }
+    ctx->graph_sets.push_back(std::move(gs));
     ctx->timings.graph_records += 1;
-    set = &gs;
+    set = &ctx->graph_sets.back();
   }
 
   for (uint32_t r = 0; r < rounds; ++r)
@@ -892,6 +954,17 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const Mi
       if (sl.zero_buf != 2 && sl.zero_buf != first_buf)  // other launches ran in between: zero the buffer the chain starts in
         MIP_HIP(ctx, hipMemsetAsync(sl.d_status + ctx->acc1_offset_words + (size_t)first_buf * ctx->groups_cap * mip::kAccStrideWords, 0,
                                     (size_t)ctx->groups_cap * mip::kAccStrideWords * 8, sl.stream));
+      // this replay's frames -> a free staging half -> the ring (stream-ordered behind the previous replay)
+      const uint32_t half = sl.stage_next;
+      sl.stage_next ^= 1u;
+      MIP_HIP(ctx, hipEventSynchronize(sl.stage_free[half]));  // the copy that last read this half has finished (no-op if never recorded)
+      uint32_t* stage = sl.h_frame_stage + (size_t)half * G * mip::kFrameWords;
+      for (uint32_t j = 0; j < G; ++j) {
+        const uint64_t step = (uint64_t)first_step + (uint64_t)r * G * F + i + (uint64_t)j * F;
+        frame_words(frames[step % n_frames], stage + (size_t)j * mip::kFrameWords);
+      }
+      MIP_HIP(ctx, hipMemcpyAsync(sl.d_frame_ring, stage, (size_t)G * mip::kFrameWords * 4, hipMemcpyHostToDevice, sl.stream));
+      MIP_HIP(ctx, hipEventRecord(sl.stage_free[half], sl.stream));
       MIP_HIP(ctx, hipGraphLaunch(fg.exec, sl.stream));
       sl.last_tag = fg.base_epoch + G;
       if (sl.epoch < sl.last_tag) sl.epoch = sl.last_tag;
@@ -902,9 +975,11 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frame, const Mi
   return MIP_OK;
 }
 
-int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* outputs, uint32_t n_outputs, uint32_t steps) {
+int32_t mip_run_many(MipContext* ctx, const MipFrame* frames, uint32_t n_frames, const MipOutputs* outputs, uint32_t n_outputs,
+                     uint32_t steps) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
-  if (!frame || !outputs || n_outputs == 0) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/outputs is NULL or empty");
+  if (!frames || n_frames == 0 || !outputs || n_outputs == 0)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frames/outputs is NULL or empty");
   bool plain = true;  // only launches of the instance kernel alone are recorded
   for (uint32_t k = 0; k < n_outputs; ++k) {
     if ((outputs[k].flags & (MIP_OUT_DEVICE | MIP_OUT_ASYNC)) != (MIP_OUT_DEVICE | MIP_OUT_ASYNC))
@@ -924,16 +999,16 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
       const uint32_t rounds = steps / round;
       if (rounds) {
         for (uint32_t k = 0; k < n_outputs; ++k)
-          if (int32_t rc = validate_run(ctx, frame, &outputs[k])) return rc;
+          if (int32_t rc = validate_run(ctx, &frames[0], &outputs[k])) return rc;
         if (int32_t rc = bind_device(ctx)) return rc;
-        if (int32_t rc = run_many_graphed(ctx, frame, outputs, n_outputs, rounds, round / F)) return rc;
+        if (int32_t rc = run_many_graphed(ctx, frames, n_frames, 0, outputs, n_outputs, rounds, round / F)) return rc;
         done = rounds * round;
       }
     }
   }
   // the rest (or everything) one launch at a time; round % n_outputs == 0 keeps the rotation
   for (uint32_t k = done; k < steps; ++k)
-    if (int32_t rc = mip_run(ctx, frame, &outputs[k % n_outputs])) return rc;
+    if (int32_t rc = mip_run(ctx, &frames[k % n_frames], &outputs[k % n_outputs])) return rc;
   return MIP_OK;
 }
 
@@ -962,12 +1037,21 @@ static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const Mi
     }
   } else {
     if (ctx->view_states.empty()) {
-      ctx->view_states.resize(mip::kMaxViews);
-      for (auto& vs : ctx->view_states) {
-        vs.stream = stream;  // not owned
-        MIP_HIP(ctx, hipMalloc(&vs.d_status, ctx->status_bytes));
-        MIP_HIP(ctx, hipMemsetAsync(vs.d_status, 0, ctx->status_bytes, stream));
+      // built aside: a failed allocation must not leave entries with a null prefix state behind
+      std::vector<MipContext::FrameSlot> states(mip::kMaxViews);
+      const int32_t rc = [&]() -> int32_t {
+        for (auto& vs : states) {
+          vs.stream = stream;  // not owned
+          MIP_HIP(ctx, hipMalloc(&vs.d_status, ctx->status_bytes));
+          MIP_HIP(ctx, hipMemsetAsync(vs.d_status, 0, ctx->status_bytes, stream));
+        }
+        return MIP_OK;
+      }();
+      if (rc != MIP_OK) {
+        for (auto& vs : states) (void)hipFree(vs.d_status);
+        return rc;
       }
+      ctx->view_states = std::move(states);
     }
     mip::ViewsArgs a{};
     a.pos = ctx->d_pos; a.rot = ctx->d_rot; a.scale = ctx->d_scale; a.mesh_id = ctx->d_mesh_id;
@@ -1149,34 +1233,47 @@ int32_t mip_wait(MipContext* ctx) {
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   ctx->pending_async = false;
-  return check_device_error(ctx);
+  const int32_t rc = check_device_error(ctx);
+  ctx->sharded_pending = 0;
+  return rc;
+}
+
+static int32_t enqueue_merge(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                             uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count) {
+  mip::MergeArgs a{};
+  a.chunks = (const unsigned char*)chunks;
+  a.stride = chunk_stride_bytes;
+  a.n_chunks = n_chunks;
+  const uint64_t fits = (chunk_stride_bytes - sizeof(MipShardHeader)) / 20u;
+  a.capacity = (chunk_capacity && chunk_capacity < fits) ? chunk_capacity : (uint32_t)(fits > 0xffffffffull ? 0xffffffffull : fits);
+  a.out_cmds = (uint32_t*)out_cmds;
+  a.out_count = out_count;
+  a.error_flag = ctx->d_error;
+  // Sized for the payload the chunks can hold: every thread moves ~8 words.
+  const uint64_t max_words = (uint64_t)a.capacity * 5u * n_chunks;
+  uint32_t blocks = (uint32_t)((max_words + 256 * 8 - 1) / (256 * 8));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(mip::mip_merge_draw_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+  MIP_HIP(ctx, hipGetLastError());
+  return MIP_OK;
 }
 
 int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
-                             void* out_cmds, uint32_t* out_count, int32_t async) {
+                             uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!chunks || !out_cmds || !out_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (n_chunks == 0 || n_chunks > mip::kMaxMergeChunks)
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_chunks %u outside 1..%u", n_chunks, mip::kMaxMergeChunks);
   if (chunk_stride_bytes < sizeof(MipShardHeader) || (chunk_stride_bytes & 3u))
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad chunk stride");
+  if ((uint64_t)chunk_capacity * 20u + sizeof(MipShardHeader) > chunk_stride_bytes)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "chunk_capacity %u does not fit a stride of %llu bytes", chunk_capacity,
+                (unsigned long long)chunk_stride_bytes);
   if (int32_t rc = bind_device(ctx)) return rc;
-  mip::MergeArgs a{};
-  a.chunks = (const unsigned char*)chunks;
-  a.stride = chunk_stride_bytes;
-  a.n_chunks = n_chunks;
-  a.out_cmds = (uint32_t*)out_cmds;
-  a.out_count = out_count;
-  a.error_flag = ctx->d_error;
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0 && !async;
   if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  // Sized for the payload the stride can hold: every thread moves ~8 words.
-  const uint64_t max_words = (chunk_stride_bytes - sizeof(MipShardHeader)) / 4 * n_chunks;
-  uint32_t blocks = (uint32_t)((max_words + 256 * 8 - 1) / (256 * 8));
-  if (blocks < 1) blocks = 1;
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(mip::mip_merge_draw_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
-  MIP_HIP(ctx, hipGetLastError());
+  if (int32_t rc = enqueue_merge(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count)) return rc;
   if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (async) {
     ctx->pending_async = true;
@@ -1245,6 +1342,14 @@ int32_t mip_comm_destroy(MipContext* ctx) {
   return MIP_OK;
 }
 
+static int32_t sharded_gather_and_merge(MipContext* ctx, uint32_t cap, void* out_cmds, uint32_t* out_count) {
+  const uint64_t stride = (sizeof(MipShardHeader) + (uint64_t)cap * 20 + 255) / 256 * 256;
+  // ONE all-gather of the fixed-size chunks, then the merge — same stream, no host round trip
+  const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
+  if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
+  return enqueue_merge(ctx, ctx->d_recv, ctx->comm_world, stride, cap, out_cmds, out_count);
+}
+
 int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipShardedOutputs* out) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!frame || !out || !out->draw_cmds || !out->draw_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out/draw_cmds/draw_count is NULL");
@@ -1252,7 +1357,6 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   if (!(out->flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_sharded needs MIP_OUT_DEVICE");
   const uint32_t cap_max = ctx->max_instances ? ctx->max_instances : 1;
   const uint32_t cap = (out->chunk_capacity && out->chunk_capacity < cap_max) ? out->chunk_capacity : cap_max;
-  const uint64_t stride = (sizeof(MipShardHeader) + (uint64_t)cap * 20 + 255) / 256 * 256;
   // 1. this rank's shard, written straight into its chunk (the send buffer always holds max_instances commands)
   MipOutputs local{};
   local.model = out->model;
@@ -1268,12 +1372,84 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   ctx->next_slot = 0;
   if (int32_t rc = mip_run(ctx, frame, &local)) return rc;
   ctx->next_slot = 0;
-  // 2. ONE all-gather of the fixed-size chunks, 3. merge — same stream, no host round trip
-  const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
-  if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
-  const bool async = (out->flags & MIP_OUT_ASYNC) != 0;
-  return mip_merge_draw_lists(ctx, ctx->d_recv, ctx->comm_world, stride, out->draw_cmds, out->draw_count, async ? 1 : 0);
+  // 2. all-gather, 3. merge
+  if (int32_t rc = sharded_gather_and_merge(ctx, cap, out->draw_cmds, out->draw_count)) return rc;
+  ctx->sharded_out_cmds = out->draw_cmds;
+  ctx->sharded_out_count = out->draw_count;
+  ctx->sharded_pending += 1;
+  if (out->flags & MIP_OUT_ASYNC) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  return mip_wait(ctx);
 }
+
+int32_t mip_import_external_fd(MipContext* ctx, int32_t fd, uint64_t size_bytes, void** out_device_ptr) {
+  if (out_device_ptr) *out_device_ptr = nullptr;
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (fd < 0 || size_bytes == 0 || !out_device_ptr) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad fd / size / out pointer");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  hipExternalMemoryHandleDesc hd{};
+  hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+  hd.handle.fd = fd;
+  hd.size = size_bytes;
+  hipExternalMemory_t mem = nullptr;
+  hipError_t e = hipImportExternalMemory(&mem, &hd);
+  if (e != hipSuccess) return fail(ctx, MIP_ERR_DEVICE, "hipImportExternalMemory(OpaqueFd, %llu bytes) failed: %s", (unsigned long long)size_bytes, hipGetErrorString(e));
+  hipExternalMemoryBufferDesc bd{};
+  bd.offset = 0;
+  bd.size = size_bytes;
+  void* ptr = nullptr;
+  e = hipExternalMemoryGetMappedBuffer(&ptr, mem, &bd);
+  if (e != hipSuccess || !ptr) {
+    (void)hipDestroyExternalMemory(mem);
+    return fail(ctx, MIP_ERR_DEVICE, "hipExternalMemoryGetMappedBuffer failed: %s", hipGetErrorString(e));
+  }
+  ctx->externals.push_back({mem, ptr});
+  *out_device_ptr = ptr;
+  return MIP_OK;
+}
+
+int32_t mip_release_external(MipContext* ctx, void* device_ptr) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < ctx->externals.size(); ++i)
+    if (ctx->externals[i].ptr == device_ptr) {
+      if (int32_t rc = bind_device(ctx)) return rc;
+      if (int32_t rc = sync_all(ctx)) return rc;
+      MIP_HIP(ctx, hipDestroyExternalMemory(ctx->externals[i].mem));
+      ctx->externals.erase(ctx->externals.begin() + (long)i);
+      return MIP_OK;
+    }
+  return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a pointer returned by mip_import_external_fd");
+}
+
+}  // extern "C"
+
+namespace {
+// A merge found a chunk whose header count exceeds the exchanged capacity (a tightened chunk and a
+// camera that moved). Every rank sees the same gathered headers, so every rank gets here for the same
+// frame: the all-gather + merge of THAT frame are repeated once at full capacity — this rank's
+// complete list is still in the send buffer — unless a later sharded frame has overwritten it.
+int32_t repair_sharded_overflow(MipContext* ctx) {
+  if (!ctx->comm || !ctx->sharded_out_cmds || ctx->sharded_pending != 1) {
+    ctx->sharded_pending = 0;
+    return fail(ctx, MIP_ERR_CAPACITY,
+                "a shard's draw list is longer than the exchanged chunk holds; merged list truncated%s",
+                ctx->comm ? " (more than one sharded frame was in flight: the overflowing one can no longer be re-sent)" : "");
+  }
+  ctx->sharded_pending = 0;
+  const uint32_t cap_max = ctx->max_instances ? ctx->max_instances : 1;
+  if (int32_t rc = sharded_gather_and_merge(ctx, cap_max, ctx->sharded_out_cmds, ctx->sharded_out_count)) return rc;
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timings.sharded_retries += 1;
+  const uint32_t e = *(volatile uint32_t*)ctx->h_error;
+  *(volatile uint32_t*)ctx->h_error = 0;
+  if (e) return fail(ctx, MIP_ERR_DEVICE, "sharded repair failed (device error word %u)", e);
+  return MIP_OK;
+}
+}  // namespace
+
+extern "C" {
 
 const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "null context"; }
 

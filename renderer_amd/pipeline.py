@@ -213,14 +213,32 @@ class InstancePipeline:
         if rc != 0:
             self._check(rc)
 
-    def run_many(self, frame, prepared_outputs, steps):
-        """`steps` frames issued from compiled code, rotating over the prepared output sets."""
+    def run_many(self, frames, prepared_outputs, steps):
+        """`steps` frames issued from compiled code: step k runs frames[k % len(frames)] into
+        prepared_outputs[k % len(prepared_outputs)]. `frames` is one MipFrame or a sequence of them (a moving
+        camera); recorded launch graphs are reused whatever the frames are."""
+        if isinstance(frames, MipFrame):
+            frames = [frames]
+        fr = (MipFrame * len(frames))()
+        for k, f in enumerate(frames):
+            C.memmove(C.addressof(fr[k]), C.addressof(f), C.sizeof(MipFrame))
         arr = (MipOutputs * len(prepared_outputs))()
         for k, o in enumerate(prepared_outputs):
             C.memmove(C.addressof(arr[k]), C.addressof(o), C.sizeof(MipOutputs))
-        rc = self._lib.mip_run_many(self._ctx, C.addressof(frame), C.addressof(arr), len(prepared_outputs), int(steps))
+        rc = self._lib.mip_run_many(self._ctx, C.addressof(fr), len(frames), C.addressof(arr), len(prepared_outputs), int(steps))
         if rc != 0:
             self._check(rc)
+
+    # -- zero-copy interop (row f-2) --
+    def import_external_fd(self, fd, size_bytes):
+        """Maps memory another API exported as an fd (VK_KHR_external_memory_fd / a dma-buf) into this
+        context's device; returns the device pointer. The fd belongs to the driver afterwards."""
+        ptr = C.c_void_p()
+        self._check(self._lib.mip_import_external_fd(self._ctx, int(fd), int(size_bytes), C.byref(ptr)))
+        return ptr.value
+
+    def release_external(self, ptr):
+        self._check(self._lib.mip_release_external(self._ctx, ptr))
 
     # -- native sharded exchange (RCCL opened by the library itself) --
     @staticmethod
@@ -256,9 +274,11 @@ class InstancePipeline:
         self._check(self._lib.mip_wait(self._ctx))
 
     def merge_draw_lists(self, chunks_ptr, n_chunks, chunk_stride_bytes, out_cmds_ptr, out_count_ptr,
-                         async_=False):
+                         async_=False, chunk_capacity=0):
+        """chunk_capacity = commands one chunk may carry (out_cmds has room for n_chunks x that); 0 = what
+        the stride holds. A chunk whose header count exceeds it is cut and reported (MIP_ERR_CAPACITY)."""
         self._check(self._lib.mip_merge_draw_lists(self._ctx, chunks_ptr, int(n_chunks),
-                                                   int(chunk_stride_bytes), out_cmds_ptr,
+                                                   int(chunk_stride_bytes), int(chunk_capacity), out_cmds_ptr,
                                                    out_count_ptr, 1 if async_ else 0))
 
     # -- extension: skinned instances (BASELINE config 5; not a reference behaviour) --

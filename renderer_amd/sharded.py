@@ -7,11 +7,20 @@ Every rank contributes one fixed-size chunk [MipShardHeader | capacity x 20-B co
 pipeline kernel writes count / index total / commands straight into that chunk, so a frame is
 kernel -> all_gather_into_tensor -> merge kernel with no host round trip. The capacity
 defaults to the shard size and can be tightened from the counts a previous frame produced
-(`tighten`); a frame that overflows it is reported (MIP_ERR_CAPACITY), never silently cut.
+(`tighten`). A frame that overflows a tightened chunk (the camera moved) is not lost: every rank
+sees the same gathered headers, so every rank's merge reports the overflow, and `complete()`
+repeats that frame's all-gather + merge once at full capacity — this rank's complete list is
+still in its send buffer — before handing the result out.
+
+No multi-GPU scaling curve exists for this path yet: it has run with world size 1 on an MI355X and
+with world sizes 2 and 3 under gloo on CPU; N = 2/4/8 numbers come from the round-end driver.
 """
 import numpy as np
 
+from ._lib import MipError
 from .pipeline import SHARD_HEADER_BYTES, make_frame
+
+MIP_ERR_CAPACITY = -4
 
 CMD_BYTES = 20
 ALLGATHER_MIN_INSTANCES = 1_000_000  # north star: exchange the draw list only at >= 1 M instances
@@ -47,6 +56,8 @@ class DrawListExchange:
         # the kernel may emit up to n_local commands, so the send buffer always has room for all of them
         self._send_full = torch.zeros(chunk_stride_bytes(self.n_local) // 4, dtype=torch.int32, device=device)
         self.merged_count = torch.zeros(2, dtype=torch.int32, device=device)
+        self.retries = 0       # frames re-gathered at full capacity after a tightened chunk overflowed
+        self._in_flight = 0    # frames issued since the last complete()
         self.set_capacity(self.n_local if capacity is None else capacity)
 
     def set_capacity(self, capacity):
@@ -67,9 +78,33 @@ class DrawListExchange:
         self.pipe.run_device(frame, model=model, visible_bitmap=visible_bitmap, world_aabb=world_aabb,
                              draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4,
                              async_=True)
+        self._gather_and_merge()
+        self._in_flight += 1
+
+    def _gather_and_merge(self):
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         self.pipe.merge_draw_lists(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(),
-                                   self.merged_count.data_ptr(), async_=True)
+                                   self.merged_count.data_ptr(), async_=True, chunk_capacity=self.capacity)
+
+    def complete(self):
+        """Block until the frames issued so far are done. If the LAST one overflowed its tightened chunk,
+        repeat its all-gather + merge at full capacity (collective: the overflow is visible in the headers
+        every rank gathered, so every rank takes this branch together). Returns True if it had to."""
+        in_flight, self._in_flight = self._in_flight, 0
+        try:
+            self.pipe.wait()
+            return False
+        except MipError as e:
+            if e.code != MIP_ERR_CAPACITY:
+                raise
+            if in_flight != 1:
+                raise MipError(e.code, "a tightened chunk overflowed with several frames in flight: the overflowing "
+                                       "frame's list has been overwritten; call complete() after every frame") from e
+        self.set_capacity(self.n_local)
+        self._gather_and_merge()
+        self.pipe.wait()
+        self.retries += 1
+        return True
 
     # -- host-side views (synchronising) --
     def local_count(self):
@@ -91,6 +126,7 @@ class DrawListExchange:
     def merged_draw_list(self):
         from .pipeline import DRAW_CMD_DTYPE
 
+        self.complete()
         total, index_total = (int(x) & 0xFFFFFFFF for x in self.merged_count.cpu().tolist())
         cmds = self.merged[:total].cpu().numpy().view(np.uint32).reshape(-1).view(DRAW_CMD_DTYPE)
         return cmds.copy(), total, index_total
@@ -105,22 +141,34 @@ class PipelinedExchange:
         if torch is None:
             import torch
         self.torch = torch
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(frames)]
-        self.pipes = [make_pipe(st.cuda_stream) for st in self.streams]
+        self.on_gpu = getattr(device, "type", str(device)) == "cuda"
+        # on a GPU every frame slot has its own stream; the CPU tests (gloo) run the same rotation on the host
+        self.streams = [torch.cuda.Stream(device=device) if self.on_gpu else None for _ in range(frames)]
+        self.pipes = [make_pipe(st.cuda_stream if st is not None else 0) for st in self.streams]
         self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group)
                           for p in self.pipes]
         self.next = 0
 
     def step(self, frame, outs_per_frame):
+        """Issues one frame on the next slot. A slot is reused every `frames` steps: its previous frame is
+        completed first (and repaired if its tightened chunk overflowed), so no list is ever overwritten
+        before it has been handed out."""
         k = self.next
         self.next = (k + 1) % len(self.exchanges)
-        with self.torch.cuda.stream(self.streams[k]):
-            self.exchanges[k].step(frame, outs_per_frame[k])
+        ex = self.exchanges[k]
+        if ex.capacity < ex.n_local and ex._in_flight:
+            ex.complete()
+        if self.on_gpu:
+            with self.torch.cuda.stream(self.streams[k]):
+                ex.step(frame, outs_per_frame[k])
+        else:
+            ex.step(frame, outs_per_frame[k])
         return k
 
     def wait(self):
-        for p in self.pipes:
-            p.wait()
+        """Drains every frame slot; a slot whose last frame overflowed its tightened chunk is repaired
+        (DrawListExchange.complete). Collective, like step()."""
+        return [ex.complete() for ex in self.exchanges]
 
     def tighten(self, margin=1.0625):
         return [ex.tighten(margin) for ex in self.exchanges]

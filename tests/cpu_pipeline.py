@@ -37,12 +37,24 @@ class OraclePipeline:
             if draw_index_total:
                 _view(draw_index_total, 4, np.uint32)[0] = r["draw_index_total"]
 
-    def merge_draw_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False):
+    def wait(self):
+        """As mip_wait: reports a deferred MIP_ERR_CAPACITY of an (async) merge."""
+        if getattr(self, "_overflow", False):
+            self._overflow = False
+            from renderer_amd._lib import MipError
+
+            raise MipError(-4, "a shard's draw list is longer than the exchanged chunk holds; merged list truncated")
+
+    def merge_draw_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0):
         lists, totals = [], []
+        fits = (stride - SHARD_HEADER_BYTES) // 20
+        capacity = min(chunk_capacity, fits) if chunk_capacity else fits
         for k in range(n_chunks):
             h = _view(chunks_ptr + k * stride, 8, np.uint32)
             count = int(h[0])
-            assert SHARD_HEADER_BYTES + count * 20 <= stride, "chunk overflow"
+            if count > capacity:  # what mip_merge_draw_lists_kernel does: cut there and raise the flag
+                count = capacity
+                self._overflow = True
             lists.append(_view(chunks_ptr + k * stride + SHARD_HEADER_BYTES, count * 20, np.uint8).view(DRAW_CMD_DTYPE).copy())
             totals.append(int(h[1]))
         merged, index_total = oracle.merge_draw_lists(lists, totals)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mip_abi_version() == 1
+    assert lib.mip_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.MipConfig) == 32
     assert C.sizeof(_lib.MipFrame) == 24 * 4 + 3 * 4 + 8 + 64
     assert C.sizeof(_lib.MipOutputs) == 6 * 8 + 8 + 16 + 8
-    assert C.sizeof(_lib.MipTimings) == 64
+    assert C.sizeof(_lib.MipTimings) == 80
     assert MESH_DTYPE.itemsize == 80 and DRAW_CMD_DTYPE.itemsize == 20
     # compile the header as C and compare sizeof/offsetof with the Python mirrors
     src = r'''
@@ -59,7 +59,7 @@ def test_struct_layouts_match_header():
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [32, 80, 180, 80, 64, 20, 32, 76, 48]
+    assert sizes == [32, 80, 180, 80, 80, 20, 32, 76, 48]
     assert MESH_DTYPE.fields["vertex_offset"][1] == 76
 
 
@@ -133,4 +133,11 @@ def test_rust_binding_sizes_and_symbols_follow_the_header():
     assert {k: int(v) for k, v in guards.items()} == want
     rust_fns = set(re.findall(r"pub fn (mip_[a-z_]+)\(", text))
     assert rust_fns <= set(_declared_functions())
-    assert {"mip_create", "mip_run", "mip_run_many", "mip_set_geometry", "mip_merge_draw_lists"} <= rust_fns
+    assert {"mip_create", "mip_run", "mip_run_many", "mip_set_geometry", "mip_merge_draw_lists",
+            "mip_import_external_fd", "mip_release_external"} <= rust_fns
+    # argument counts of the calls whose signature changed with ABI 2 (header vs Rust extern block)
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for fn in ("mip_run_many", "mip_merge_draw_lists", "mip_import_external_fd"):
+        c_args = re.search(fn + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S).group(1).count(",") + 1
+        r_args = re.search(r"pub fn " + fn + r"\((.*?)\)\s*->", text, flags=re.S).group(1).count(",") + 1
+        assert c_args == r_args, (fn, c_args, r_args)

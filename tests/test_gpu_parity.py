@@ -264,6 +264,22 @@ def test_merge_draw_lists_on_device(ra, oracle_mod):
         with pytest.raises(ra.MipError) as e:
             p.merge_draw_lists(recv.data_ptr(), 1, small, merged.data_ptr(), count.data_ptr())
         assert e.value.code == -4
+        # the stride is rounded up to 256 B and physically holds a few commands more than the capacity the
+        # caller sized its output for: a count of capacity + 1 is cut at the CAPACITY and reported, and
+        # nothing lands past n_chunks x capacity commands
+        n0 = int(recv[0].item())                       # shard 0's count
+        cap0 = n0 - 1
+        stride0 = chunk_stride_bytes(cap0)
+        assert (stride0 - 32) // 20 >= n0               # ... although it would fit the padded stride
+        out = torch.full((cap0 + 8, 5), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        with pytest.raises(ra.MipError) as e:
+            p.merge_draw_lists(recv.data_ptr(), 1, stride0, out.data_ptr(), count.data_ptr(), chunk_capacity=cap0)
+        assert e.value.code == -4
+        assert int(count[0].item()) == cap0 and bool((out[cap0:] == -1).all())
+        assert out[:cap0].cpu().numpy().tobytes() == want["draw_cmds"][:cap0].tobytes()
+        with pytest.raises(ra.MipError):                # a capacity the stride cannot hold is an argument error
+            p.merge_draw_lists(recv.data_ptr(), 1, small, out.data_ptr(), count.data_ptr(), chunk_capacity=1000)
 
 
 def test_config4_ten_million_in_eight_shards(ra, oracle_mod):
@@ -941,9 +957,26 @@ def test_native_rccl_exchange_world_size_one(ra, oracle_mod):
             got = merged[:total].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
             assert got.tobytes() == want["draw_cmds"].tobytes()
             assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"])
-        with pytest.raises(ra.MipError) as e:   # a chunk smaller than the rank's list is reported
-            p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), chunk_capacity=1000)
+        # a chunk smaller than the rank's list: the frame is NOT lost — the library re-gathers it at full
+        # capacity (synchronous call: at once; asynchronous call: inside mip_wait)
+        for async_ in (False, True):
+            merged.zero_(); count.zero_(); torch.cuda.synchronize()
+            before = p.timings()["sharded_retries"]
+            p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), chunk_capacity=1000, async_=async_)
+            if async_:
+                p.wait()
+            assert p.timings()["sharded_retries"] == before + 1
+            total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
+            assert total == want["draw_count"] and index_total == want["draw_index_total"]
+            assert merged[:total].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+        # two overflowing frames queued before a wait: the first one's list is gone — reported, not repaired
+        p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), chunk_capacity=1000, async_=True)
+        p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), chunk_capacity=1000, async_=True)
+        with pytest.raises(ra.MipError) as e:
+            p.wait()
         assert e.value.code == -4
+        p.run_sharded(frame, merged.data_ptr(), count.data_ptr())  # and the context is fine afterwards
+        assert int(count[0].item()) == want["draw_count"]
         p.comm_destroy()
     with ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=2) as p2:
         with pytest.raises(ra.MipError):

@@ -1,0 +1,232 @@
+"""Round-2 additions, all through the C ABI on the GPU: launch graphs that survive a moving camera,
+the upload-time finite census that picks the kernel, both store/command orders of the kernel, and
+zero-copy import of another process's allocation (row f-2)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import assert_parity, run_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import renderer_amd
+
+    renderer_amd.load_library()  # fails loudly if the HIP library is missing
+    return renderer_amd
+
+
+def _camera_path(s, k_frames):
+    """k frames of a camera that translates and yaws: planes from the oracle's project_camera."""
+    import oracle
+
+    out = []
+    for k in range(k_frames):
+        t = k / max(k_frames - 1, 1)
+        pos = np.array([-20.0 + 40.0 * t, 1.0 + 3.0 * np.sin(7 * t), 2.0 - 30.0 * t], np.float32)
+        half = 0.5 * (0.9 * np.sin(5.0 * t))
+        rot = np.array([0.0, np.sin(half), 0.0, np.cos(half)], np.float32)  # [i,j,k,w]
+        out.append((oracle.project_camera(pos, rot), pos))
+    return out
+
+
+def test_moving_camera_replays_one_recorded_graph(ra, oracle_mod, monkeypatch):
+    """mip_run_many with a different MipFrame every step (the renderer's frame loop: project_camera
+    runs every frame, src/ecs.rs:66-91): the launches are recorded ONCE, every replay carries new
+    planes through the device-side frame ring, and every frame's bitmap and command list is the
+    oracle's for that frame's camera."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=8_000)
+    n, K = s["n"], 256
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("MIP_TUNE_GRAPH_ROUND", str(2 * K))  # one round = 2 K frames = two passes over K output sets
+    with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+        monkeypatch.delenv("MIP_TUNE_GRAPH_ROUND")
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        cmds = torch.zeros((K, n, 5), dtype=torch.int32, device=dev)
+        scal = torch.zeros((K, 8), dtype=torch.int32, device=dev)
+        bits = torch.zeros((K, (n + 31) // 32), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        outs = [p.prepare_outputs(draw_cmds=cmds[k].data_ptr(), draw_count=scal[k].data_ptr(),
+                                  draw_index_total=scal[k].data_ptr() + 4, visible_bitmap=bits[k].data_ptr())
+                for k in range(K)]
+        for rep in range(2):  # the second call moves the camera along a different path: same graphs
+            path = _camera_path(s, 2 * K)
+            if rep:
+                path = path[::-1]
+            frames = [make_frame(pl, pos) for pl, pos in path]
+            p.run_many(frames, outs, 2 * K)
+            p.wait()
+            t = p.timings()
+            assert t["graph_records"] == 1 and t["graph_frames"] == (rep + 1) * 2 * K, t
+            counts = scal[:, 0].cpu().numpy()
+            assert len(set(counts.tolist())) > K // 4  # the camera really moved
+            for k in range(K):  # output set k holds step K + k of this call
+                pl, pos = path[K + k]
+                want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], pl, pos,
+                                      want=("visible_bitmap", "draw_cmds"))
+                c = int(counts[k])
+                assert c == want["draw_count"] and int(scal[k, 1].item()) == want["draw_index_total"], (rep, k)
+                assert np.array_equal(bits[k].cpu().numpy().view(np.uint32), want["visible_bitmap"]), (rep, k)
+                assert cmds[k, :c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), (rep, k)
+        # two frames in flight, four output sets, default round: still one recording per context
+    with ra.InstancePipeline(max_instances=n, max_meshes=64, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        outs4 = outs[:4]
+        path = _camera_path(s, 192)
+        p.run_many([make_frame(pl, pos) for pl, pos in path], outs4, 192)
+        p.wait()
+        t = p.timings()
+        assert t["graph_records"] == 1 and t["graph_frames"] == 192, t
+        for k in range(4):  # the last four steps
+            pl, pos = path[188 + k]
+            want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], pl, pos, want=("draw_cmds",))
+            c = int(scal[k, 0].item())
+            assert c == want["draw_count"] and cmds[k, :c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), k
+
+
+def test_finite_census_picks_the_kernel(ra, oracle_mod):
+    """Uploads are scanned once with the kernel's own finite test. All finite: the frame runs the kernel
+    without the literal cold path (general_launches stays 0). One NaN / inf / overflowing quaternion
+    anywhere: the kernel with that path. Partial updates keep the count exact in both directions."""
+    s = ra.scene.make_scene(3, n=30_000)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), "finite")
+        assert p.timings()["general_launches"] == 0
+        for what, col, row, val in (("nan position", "pos", 12_345, [np.nan, 1.0, 2.0]),
+                                    ("inf scale", "scale", 77, np.inf),
+                                    ("huge quaternion", "rot", 29_999, [3e19, 3e19, 0.0, 1.0])):  # w*w, i*i overflow
+            old = s[col][row].copy()
+            s[col][row] = val
+            kw = {"pos": "pos_xyz", "rot": "rot_ijkw", "scale": "scale"}[col]
+            p.update_instances(row, **{kw: s[col][row:row + 1]})
+            before = p.timings()["general_launches"]
+            assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), what)
+            assert p.timings()["general_launches"] == before + 1, what
+            s[col][row] = old
+            p.update_instances(row, **{kw: s[col][row:row + 1]})
+            before = p.timings()["general_launches"]
+            assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), what + " restored")
+            assert p.timings()["general_launches"] == before, what
+        # two bad instances, one repaired: still the general kernel
+        s["pos"][5] = np.nan
+        s["pos"][6] = np.inf
+        p.update_instances(5, pos_xyz=s["pos"][5:7])
+        s["pos"][5] = 0.0
+        p.update_instances(5, pos_xyz=s["pos"][5:6])
+        before = p.timings()["general_launches"]
+        assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), "one of two repaired")
+        assert p.timings()["general_launches"] == before + 1
+
+
+@pytest.mark.parametrize("order", [1, 3])
+@pytest.mark.parametrize("general", [0, 1])
+def test_both_kernel_orders_and_both_arithmetic_paths(ra, oracle_mod, order, general, monkeypatch):
+    """The host picks the store/command order by launch size and the arithmetic variant by the census;
+    every combination has to give the same bytes (forced here on sizes either side of the switch)."""
+    monkeypatch.setenv("MIP_TUNE_ORDER", str(order))
+    monkeypatch.setenv("MIP_TUNE_FORCE_GENERAL", str(general))
+    for n in (1, 255, 257, 70_001):
+        s = ra.scene.make_scene(3, n=n)
+        with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), (order, general, n))
+
+
+_EXPORTER = r'''
+import ctypes as C, os, socket, sys
+import numpy as np, torch
+sock_path, nbytes = sys.argv[1], int(sys.argv[2])
+buf = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda:0")
+torch.cuda.synchronize()
+hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+hip.hipMemGetHandleForAddressRange.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_ulonglong]
+hip.hipMemGetHandleForAddressRange.restype = C.c_int
+fd = C.c_int(-1)
+rc = hip.hipMemGetHandleForAddressRange(C.byref(fd), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel() * 4), 1, 0)  # hipMemRangeHandleTypeDmaBufFd
+s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+s.connect(sock_path)
+if rc != 0 or fd.value < 0:
+    s.sendall(b"EXPORT_FAILED %d" % rc); sys.exit(0)
+socket.send_fds(s, [b"FD"], [fd.value])
+assert s.recv(16) == b"DONE"           # the importer has run its frame and waited for it
+torch.cuda.synchronize()
+host = buf.cpu().numpy()
+s.sendall(len(host.tobytes()).to_bytes(8, "little") + host.tobytes())
+s.close()
+'''
+
+
+def test_external_memory_fd_import_zero_copy(ra, oracle_mod, tmp_path):
+    """Row f-2, the HIP half: a buffer that ANOTHER process allocated (standing in for the renderer's VMA
+    allocation exported with vkGetMemoryFdKHR; on amdgpu such an fd is a dma-buf) is imported with
+    mip_import_external_fd, a frame writes its model matrices, bitmap and command list straight into it,
+    and the OWNER of the allocation reads the oracle's bytes out of its own pointer."""
+    s = ra.scene.make_scene(3, n=20_000)
+    n = s["n"]
+    want = run_oracle(oracle_mod, s, want=("model", "visible_bitmap", "draw_cmds"))
+    off_model, off_cmds, off_bits, off_scal = 0, n * 64, n * 64 + n * 20, n * 64 + n * 20 + ((n + 31) // 32) * 4
+    off_scal = (off_scal + 255) // 256 * 256
+    nbytes = (off_scal + 256 + (1 << 21) - 1) // (1 << 21) * (1 << 21)  # whole 2 MiB pages
+    sock_path = str(tmp_path / "fd.sock")
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind(sock_path)
+    srv.listen(1)
+    srv.settimeout(120)
+    child = subprocess.Popen([sys.executable, "-c", _EXPORTER, sock_path, str(nbytes)], stderr=subprocess.PIPE)
+    try:
+        conn, _ = srv.accept()
+        conn.settimeout(120)
+        msg, fds, _, _ = socket.recv_fds(conn, 64, 1)
+        if not fds:
+            pytest.fail(f"the exporter could not export a dma-buf fd: {msg!r}")
+        with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            base = p.import_external_fd(fds[0], nbytes)
+            assert base
+            from renderer_amd.pipeline import make_frame
+
+            p.run_device(make_frame(s["planes"], s["cam_pos"]), model=base + off_model, draw_cmds=base + off_cmds,
+                         visible_bitmap=base + off_bits, draw_count=base + off_scal, draw_index_total=base + off_scal + 4)
+            p.wait()
+            with pytest.raises(ra.MipError):
+                p.release_external(base + 4)
+            p.release_external(base)
+        conn.sendall(b"DONE")
+        size = int.from_bytes(_recv_exact(conn, 8), "little")
+        raw = np.frombuffer(_recv_exact(conn, size), dtype=np.uint8)
+    finally:
+        child.wait(timeout=120)
+        srv.close()
+    assert child.returncode == 0, child.stderr.read().decode()[-2000:]
+    count, index_total = (int(x) for x in raw[off_scal:off_scal + 8].view(np.uint32))
+    assert count == want["draw_count"] and index_total == want["draw_index_total"]
+    assert raw[off_model:off_model + n * 64].tobytes() == want["model"].tobytes()
+    assert raw[off_cmds:off_cmds + count * 20].tobytes() == want["draw_cmds"].tobytes()
+    assert raw[off_bits:off_bits + ((n + 31) // 32) * 4].tobytes() == want["visible_bitmap"].tobytes()
+
+
+def _recv_exact(conn, k):
+    out = bytearray()
+    while len(out) < k:
+        chunk = conn.recv(min(1 << 20, k - len(out)))
+        if not chunk:
+            raise RuntimeError("peer closed")
+        out += chunk
+    return bytes(out)

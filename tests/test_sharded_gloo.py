@@ -75,3 +75,83 @@ def test_shard_ranges_cover_everything():
             for (a, b), (c, e) in zip(spans, spans[1:]):
                 assert b == c and a <= b and c <= e
     assert chunk_stride_bytes(0) == 256 and chunk_stride_bytes(12) % 256 == 0
+
+
+def _camera_b():
+    """A second camera that sees more of the scene than the default one (so a chunk tightened on the
+    default camera's counts overflows)."""
+    import oracle
+
+    pos = np.array([0.0, 1.0, -40.0], np.float32)
+    return oracle.project_camera(pos, (0.0, 0.0, 0.0, 1.0)), pos
+
+
+def _worker_overflow(rank, world, init_file, n_global, out_dir):
+    """tighten() on camera A, then the camera moves: the overflowing frame must come out complete
+    (one collective re-gather at full capacity), on every rank, with nothing lost."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle
+    from cpu_pipeline import OraclePipeline
+    from renderer_amd import scene
+    from renderer_amd.sharded import DrawListExchange, PipelinedExchange, make_shard_frame, shard_range
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        full = scene.make_scene(3, n=n_global)
+        lo, hi = shard_range(n_global, world, rank)
+        shard = scene.make_scene(3, n=hi - lo, first=lo)
+        n_local = hi - lo
+        planes_b, cam_b = _camera_b()
+        frame_a = make_shard_frame(full["planes"], full["cam_pos"], n_global, world, rank)
+        frame_b = make_shard_frame(planes_b, cam_b, n_global, world, rank)
+        want_a = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], full["planes"], full["cam_pos"])
+        want_b = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], planes_b, cam_b)
+        assert want_b["draw_count"] > 1.2 * want_a["draw_count"]
+
+        def check(ex, want, what):
+            cmds, total, index_total = ex.merged_draw_list()
+            assert total == want["draw_count"] and index_total == want["draw_index_total"], (what, total, want["draw_count"])
+            assert cmds.tobytes() == want["draw_cmds"].tobytes(), what
+
+        ex = DrawListExchange(OraclePipeline(shard), n_local, world, rank, torch.device("cpu"), dist=dist, torch=torch)
+        ex.step(frame_a)
+        check(ex, want_a, "A, full capacity")
+        cap = ex.tighten()
+        assert cap < n_local
+        ex.step(frame_a)
+        check(ex, want_a, "A, tightened")
+        assert ex.retries == 0
+        ex.step(frame_b)                      # the camera moved between tighten() and this frame
+        check(ex, want_b, "B, overflow repaired")
+        assert ex.retries == 1 and ex.capacity == n_local
+        ex.step(frame_a)
+        check(ex, want_a, "A again")
+        assert ex.retries == 1
+
+        # the same with two frames in flight (two exchanges issued round-robin)
+        px = PipelinedExchange(lambda stream: OraclePipeline(shard), n_local, world, rank, torch.device("cpu"),
+                               frames=2, dist=dist, torch=torch)
+        for f in (frame_a, frame_a):
+            px.step(f, [None, None])
+        assert px.wait() == [False, False]
+        px.tighten()
+        for k, f in enumerate((frame_a, frame_b, frame_b, frame_a)):
+            slot = px.step(f, [None, None])
+            assert slot == k % 2
+        repaired = px.wait()                  # slot 0 last ran B, slot 1 last ran A (after B was completed inside step)
+        check(px.exchanges[0], want_b, "pipelined slot 0")
+        check(px.exchanges[1], want_a, "pipelined slot 1")
+        assert sum(e.retries for e in px.exchanges) == 2, [e.retries for e in px.exchanges]
+        assert repaired == [True, False]
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_global", [(2, 6_000), (3, 5_001)])
+def test_overflow_of_a_tightened_chunk_is_repaired_not_lost(world, n_global):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_overflow, args=(world, os.path.join(d, "init"), n_global, d), nprocs=world, join=True)
+        for r in range(world):
+            assert os.path.exists(os.path.join(d, f"ok{r}"))
