@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 static_assert(sizeof(MipDrawIndexedIndirectCommand) == 20, "VkDrawIndexedIndirectCommand is 20 bytes");
@@ -88,6 +89,12 @@ struct MipContext {
   uint32_t n_vertices = 0, n_indices = 0;
   bool have_geometry = false;
   bool geometry_finite = false;  // every uploaded position is finite (lets the triangle stage skip exact no-ops)
+  // host copies kept to check the mesh table against the geometry before the per-triangle stage gathers
+  // vertices[vertex_offset + index] and indices[index_offset ..] unchecked on the device
+  std::vector<MipMesh> h_meshes;
+  std::vector<uint32_t> h_indices;
+  int geometry_checked = 0;  // 0 = not yet, 1 = consistent, -1 = inconsistent (message in geometry_error)
+  std::string geometry_error;
   // skinned extension (mip_set_skeleton / mip_set_poses / mip_run_skinned)
   mip::JointEntry* d_joints = nullptr;
   uint32_t n_joints = 0, max_joint_depth = 0;
@@ -323,6 +330,41 @@ int32_t reset_prefix_state_if_needed(MipContext* ctx, MipContext::FrameSlot& sl,
   return MIP_OK;
 }
 
+// One pass over the LOD ranges the per-triangle stage can be sent to (LODs 0 and 1 of every mesh: pick_lod
+// never picks another): each must lie inside the uploaded index buffer, and every index in it, offset by the
+// mesh's vertex_offset, inside the uploaded vertices. Cached until either table changes.
+int32_t check_geometry(MipContext* ctx) {
+  if (ctx->geometry_checked == 0) {
+    ctx->geometry_checked = 1;
+    char buf[256];
+    for (uint32_t k = 0; k < ctx->h_meshes.size() && ctx->geometry_checked == 1; ++k) {
+      const MipMesh& m = ctx->h_meshes[k];
+      for (uint32_t l = 0; l < m.n_lods && l < 2u; ++l) {
+        const uint64_t off = m.index_offset[l], len = m.index_len[l];
+        if (off + len > ctx->n_indices) {
+          snprintf(buf, sizeof buf, "mesh %u LOD %u: indices [%llu, %llu) outside the %u uploaded indices", k, l,
+                   (unsigned long long)off, (unsigned long long)(off + len), ctx->n_indices);
+          ctx->geometry_error = buf;
+          ctx->geometry_checked = -1;
+          break;
+        }
+        uint32_t mx = 0;
+        for (uint64_t j = off; j < off + len; ++j) mx = ctx->h_indices[j] > mx ? ctx->h_indices[j] : mx;
+        if (len && (m.vertex_offset < 0 || (uint64_t)m.vertex_offset + mx >= ctx->n_vertices)) {
+          snprintf(buf, sizeof buf, "mesh %u LOD %u: vertex_offset %d + largest index %u outside the %u uploaded vertices", k, l,
+                   m.vertex_offset, mx, ctx->n_vertices);
+          ctx->geometry_error = buf;
+          ctx->geometry_checked = -1;
+          break;
+        }
+      }
+    }
+  }
+  if (ctx->geometry_checked < 0)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mesh table and geometry disagree: %s", ctx->geometry_error.c_str());
+  return MIP_OK;
+}
+
 int32_t validate_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* out) {
   if (!frame || !out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out is NULL");
   if (!ctx->have_instances || !ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "instances or mesh table not set");
@@ -337,6 +379,7 @@ int32_t validate_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
     if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
     if (!ctx->have_geometry) return fail(ctx, MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
     if (!out->model || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs model and draw_cmds");
+    if (int32_t rc = check_geometry(ctx)) return rc;
   }
   return MIP_OK;
 }
@@ -531,6 +574,8 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   }
   ctx->m = m;
   ctx->have_meshes = true;
+  ctx->h_meshes.assign(meshes, meshes + m);
+  ctx->geometry_checked = 0;
   return MIP_OK;
 }
 
@@ -571,6 +616,8 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
   for (size_t k = 0; k < (size_t)n_vertices * 3 && finite; ++k) finite = std::isfinite(vertex_xyz[k]);
   ctx->geometry_finite = finite;
   ctx->have_geometry = true;
+  ctx->h_indices.assign(indices, indices + n_indices);
+  ctx->geometry_checked = 0;
   return MIP_OK;
 }
 
@@ -1100,6 +1147,23 @@ int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs*
   if (!frames || !outs) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frames/outs is NULL");
   if (n_views == 0 || n_views > MIP_MAX_VIEWS) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_views %u outside 1..%u", n_views, (unsigned)MIP_MAX_VIEWS);
   const bool async = (outs[0].flags & MIP_OUT_ASYNC) != 0;
+  if (ctx->ordered_tiles) {
+    // The multi-view kernel numbers its tiles by blockIdx.x. A context in ordered-tiles mode (MIP_CFG_ORDERED_TILES,
+    // or after a MIP_ERR_TIMEOUT) must not depend on dispatch order: a view IS a frame, so run one ticketed frame
+    // per view on the first stream — same bytes, n_views launches.
+    for (uint32_t v = 0; v < n_views; ++v) {
+      const MipOutputs& o = outs[v];
+      if (!(o.flags & MIP_OUT_DEVICE) || !o.draw_cmds || !o.draw_count || o.model || o.world_aabb || o.tlas_instances || o.culled_index_buffer)
+        return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "view %u: mip_run_views takes MIP_OUT_DEVICE outputs with visible_bitmap, draw_cmds, draw_count, draw_index_total only", v);
+      MipOutputs one = o;
+      one.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC;
+      ctx->next_slot = 0;
+      if (int32_t rc = run_frame(ctx, &frames[v], &one, false, nullptr)) return rc;
+    }
+    ctx->next_slot = 0;
+    if (async) return MIP_OK;
+    return mip_wait(ctx);
+  }
   // four views per launch (one wave of a workgroup finishes one view); more views are more launches on the same stream
   for (uint32_t first = 0; first < n_views; first += mip::kMaxViews) {
     const uint32_t k = n_views - first < mip::kMaxViews ? n_views - first : mip::kMaxViews;

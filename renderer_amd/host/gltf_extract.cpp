@@ -30,18 +30,22 @@ int main(int argc, char** argv) {
     const uint32_t n = (uint32_t)s.scale.size(), m = (uint32_t)s.meshes.size();
     FILE* f = fopen(argv[2], "wb");
     if (!f) { perror("out"); return 2; }
-    fwrite(&n, 4, 1, f);
-    fwrite(&m, 4, 1, f);
-    fwrite(s.meshes.data(), sizeof(MipMesh), m, f);
-    fwrite(s.pos_xyz.data(), 4, s.pos_xyz.size(), f);
-    fwrite(s.rot_ijkw.data(), 4, s.rot_ijkw.size(), f);
-    fwrite(s.scale.data(), 4, s.scale.size(), f);
-    fwrite(s.mesh_id.data(), 4, s.mesh_id.size(), f);
+    // an empty vector's data() may be null, which fwrite must not be handed (found by the sanitizer fuzz)
+    auto put = [f](const void* p, size_t size, size_t count) {
+      if (count) fwrite(p, size, count, f);
+    };
+    put(&n, 4, 1);
+    put(&m, 4, 1);
+    put(s.meshes.data(), sizeof(MipMesh), m);
+    put(s.pos_xyz.data(), 4, s.pos_xyz.size());
+    put(s.rot_ijkw.data(), 4, s.rot_ijkw.size());
+    put(s.scale.data(), 4, s.scale.size());
+    put(s.mesh_id.data(), 4, s.mesh_id.size());
     const uint32_t nv = (uint32_t)(s.vertices.size() / 3), ni = (uint32_t)s.indices.size();
-    fwrite(&nv, 4, 1, f);
-    fwrite(&ni, 4, 1, f);
-    fwrite(s.vertices.data(), 4, s.vertices.size(), f);
-    fwrite(s.indices.data(), 4, s.indices.size(), f);
+    put(&nv, 4, 1);
+    put(&ni, 4, 1);
+    put(s.vertices.data(), 4, s.vertices.size());
+    put(s.indices.data(), 4, s.indices.size());
     fclose(f);
     printf("entities=%u meshes=%u primitives=%u skipped_no_base_color=%u skipped_small=%u vertices=%u indices=%u\n", n, m,
            s.primitives_seen, s.skipped_no_base_color, s.skipped_small, nv, ni);

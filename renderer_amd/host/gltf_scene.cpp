@@ -37,10 +37,32 @@ struct Json {
   size_t size() const { return kind == Array ? arr.size() : 0; }
 };
 
+// A JSON number used as an index, count, offset or stride: finite, non-negative, integral, < 2^40.
+// (Converting a negative, NaN or huge double to size_t is undefined behaviour, and every such value
+// comes straight from an untrusted file.)
+size_t to_index(const Json& j, const char* what) {
+  if (j.kind != Json::Number || !(j.num >= 0.0) || j.num >= 1099511627776.0 || j.num != std::floor(j.num))
+    throw std::runtime_error(std::string("gltf: ") + what + " is not a valid non-negative integer");
+  return (size_t)j.num;
+}
+size_t index_or(const Json& obj, const char* key, size_t fallback) {
+  const Json* j = obj.get(key);
+  return j ? to_index(*j, key) : fallback;
+}
+
 struct Parser {
   const std::string& s;
   size_t i = 0;
+  int depth = 0;  // arrays + objects open at this point: the parser recurses, so untrusted nesting is capped
+  static constexpr int kMaxDepth = 64;
   explicit Parser(const std::string& text) : s(text) {}
+  struct Nest {
+    Parser& p;
+    explicit Nest(Parser& parser) : p(parser) {
+      if (++p.depth > kMaxDepth) p.fail("nesting deeper than 64");
+    }
+    ~Nest() { --p.depth; }
+  };
   [[noreturn]] void fail(const char* what) const {
     throw std::runtime_error(std::string("gltf json: ") + what + " at byte " + std::to_string(i));
   }
@@ -107,6 +129,7 @@ struct Parser {
     return out;
   }
   Json array() {
+    const Nest nest(*this);
     Json j;
     j.kind = Json::Array;
     ++i;
@@ -122,6 +145,7 @@ struct Parser {
     }
   }
   Json object() {
+    const Nest nest(*this);
     Json j;
     j.kind = Json::Object;
     ++i;
@@ -219,6 +243,8 @@ Document open_document(const std::string& path) {
     if (!uri) {
       if (k == 0 && have_glb_bin) d.buffers.push_back(glb_bin);
       else throw std::runtime_error("gltf: buffer without uri");
+    } else if (uri->kind != Json::String || uri->str.empty() || uri->str.find("://") != std::string::npos) {
+      throw std::runtime_error("gltf: buffer uri must be a data: uri or a relative file path");
     } else if (!uri->str.compare(0, 5, "data:")) {
       const size_t comma = uri->str.find(',');
       if (comma == std::string::npos) throw std::runtime_error("gltf: bad data uri");
@@ -254,23 +280,25 @@ AccessorView view_of(const Document& d, size_t accessor_index) {
   const Json* bv_index = a.get("bufferView");
   if (!bv_index) throw std::runtime_error("gltf: accessor without bufferView");
   const Json* views = d.root.get("bufferViews");
-  if (!views || (size_t)bv_index->num >= views->size()) throw std::runtime_error("gltf: bufferView index out of range");
-  const Json& bv = views->arr[(size_t)bv_index->num];
-  const size_t buffer = (size_t)bv.number_or("buffer", 0);
+  if (!views || to_index(*bv_index, "bufferView") >= views->size()) throw std::runtime_error("gltf: bufferView index out of range");
+  const Json& bv = views->arr[to_index(*bv_index, "bufferView")];
+  const size_t buffer = index_or(bv, "buffer", 0);
   if (buffer >= d.buffers.size()) throw std::runtime_error("gltf: buffer index out of range");
   AccessorView v;
-  v.component_type = (int)a.number_or("componentType", 0);
+  v.component_type = (int)index_or(a, "componentType", 0);
   const Json* type = a.get("type");
   const std::string t = type ? type->str : "";
   v.components = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : 0;
   if (!v.components) throw std::runtime_error("gltf: unsupported accessor type " + t);
-  v.count = (size_t)a.number_or("count", 0);
+  v.count = index_or(a, "count", 0);
   const size_t elem = (size_t)component_size(v.component_type) * v.components;
-  v.stride = (size_t)bv.number_or("byteStride", 0);
+  v.stride = index_or(bv, "byteStride", 0);
   if (!v.stride) v.stride = elem;
-  const size_t offset = (size_t)bv.number_or("byteOffset", 0) + (size_t)a.number_or("byteOffset", 0);
+  const size_t offset = index_or(bv, "byteOffset", 0) + index_or(a, "byteOffset", 0);  // each < 2^40: no wrap
   const std::string& buf = d.buffers[buffer];
-  if (v.count && offset + (v.count - 1) * v.stride + elem > buf.size()) throw std::runtime_error("gltf: accessor overruns its buffer");
+  // count, stride < 2^40 would wrap a 64-bit product: bound the count by what the buffer can hold first
+  if (v.count && (offset > buf.size() || elem > buf.size() - offset || (v.count - 1) > (buf.size() - offset - elem) / v.stride))
+    throw std::runtime_error("gltf: accessor overruns its buffer");
   v.data = (const unsigned char*)buf.data() + offset;
   return v;
 }
@@ -328,20 +356,22 @@ void decompose(const Json& node, float t[3], float r[4], float s[3]) {
 bool has_base_color_texture(const Document& d, const Json& primitive) {
   const Json* mat_index = primitive.get("material");
   const Json* materials = d.root.get("materials");
-  if (!mat_index || !materials || (size_t)mat_index->num >= materials->size()) return false;
-  const Json* pbr = materials->arr[(size_t)mat_index->num].get("pbrMetallicRoughness");
+  if (!mat_index || !materials || to_index(*mat_index, "material") >= materials->size()) return false;
+  const Json* pbr = materials->arr[to_index(*mat_index, "material")].get("pbrMetallicRoughness");
   return pbr && pbr->has("baseColorTexture");
 }
 
-void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
+void visit_node(const Document& d, size_t node_index, Scene& out, int depth, size_t& visits) {
   const Json* nodes = d.root.get("nodes");
   if (!nodes || node_index >= nodes->size()) throw std::runtime_error("gltf: node index out of range");
   if (depth > 256) throw std::runtime_error("gltf: node hierarchy too deep (cycle?)");
+  // a node graph that is not a tree (shared or cyclic children) can fan out exponentially below the depth limit
+  if (++visits > (size_t)1 << 20) throw std::runtime_error("gltf: more than 2^20 node visits (children shared or cyclic?)");
   const Json& node = nodes->arr[node_index];
   if (const Json* mesh_index = node.get("mesh")) {
     const Json* meshes = d.root.get("meshes");
-    if (!meshes || (size_t)mesh_index->num >= meshes->size()) throw std::runtime_error("gltf: mesh index out of range");
-    const Json& mesh = meshes->arr[(size_t)mesh_index->num];
+    if (!meshes || to_index(*mesh_index, "mesh") >= meshes->size()) throw std::runtime_error("gltf: mesh index out of range");
+    const Json& mesh = meshes->arr[to_index(*mesh_index, "mesh")];
     const Json* primitives = mesh.get("primitives");
     for (size_t p = 0; primitives && p < primitives->size(); ++p) {
       const Json& prim = primitives->arr[p];
@@ -353,20 +383,22 @@ void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
       const Json* attributes = prim.get("attributes");
       const Json* pos_acc = attributes ? attributes->get("POSITION") : nullptr;
       if (!pos_acc) throw std::runtime_error("gltf: primitive without POSITION");  // "failed to load positions"
-      const AccessorView positions = view_of(d, (size_t)pos_acc->num);
+      const AccessorView positions = view_of(d, to_index(*pos_acc, "POSITION"));
       if (positions.component_type != 5126 || positions.components != 3) throw std::runtime_error("gltf: POSITION must be float VEC3");
       if (positions.count < 100) {  // :677-679
         ++out.skipped_small;
         continue;
       }
-      const Json& pos_json = d.root.get("accessors")->arr[(size_t)pos_acc->num];
+      const Json& pos_json = d.root.get("accessors")->arr[to_index(*pos_acc, "POSITION")];
       const Json* mn = pos_json.get("min");
       const Json* mx = pos_json.get("max");
       if (!mn || !mx || mn->size() != 3 || mx->size() != 3) throw std::runtime_error("gltf: POSITION accessor needs min/max");
       const Json* idx_acc = prim.get("indices");
       if (!idx_acc) throw std::runtime_error("gltf: primitive without indices");  // "failed to load indices"
-      const AccessorView idx = view_of(d, (size_t)idx_acc->num);
+      const AccessorView idx = view_of(d, to_index(*idx_acc, "indices"));
       if (idx.components != 1) throw std::runtime_error("gltf: indices must be SCALAR");
+      if (positions.count > 0x7fffffffull || out.vertices.size() / 3 + positions.count > 0x7fffffffull || idx.count > 0xffffffffull)
+        throw std::runtime_error("gltf: geometry too large for 32-bit offsets");
 
       MipMesh m{};
       for (int k = 0; k < 3; ++k) {
@@ -387,6 +419,8 @@ void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
         else if (idx.component_type == 5123) { uint16_t h; std::memcpy(&h, e, 2); v = h; }
         else if (idx.component_type == 5125) std::memcpy(&v, e, 4);
         else throw std::runtime_error("gltf: indices must be unsigned");
+        // the per-triangle stage gathers vertices[vertex_offset + index] unchecked on the device
+        if (v >= positions.count) throw std::runtime_error("gltf: index " + std::to_string(v) + " outside the primitive's " + std::to_string(positions.count) + " positions");
         lod0[k] = v;
       }
       // LOD chain (:740-753): LOD 0 + up to five reduced levels kept while they shrink and are non-empty
@@ -426,7 +460,7 @@ void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
     }
   }
   if (const Json* children = node.get("children"))
-    for (size_t k = 0; k < children->size(); ++k) visit_node(d, (size_t)children->arr[k].num, out, depth + 1);
+    for (size_t k = 0; k < children->size(); ++k) visit_node(d, to_index(children->arr[k], "child"), out, depth + 1, visits);
 }
 
 }  // namespace
@@ -434,10 +468,11 @@ void visit_node(const Document& d, size_t node_index, Scene& out, int depth) {
 Scene load(const std::string& path) {
   const Document d = open_document(path);
   Scene out;
+  size_t visits = 0;
   const Json* scenes = d.root.get("scenes");
   for (size_t s = 0; scenes && s < scenes->size(); ++s) {  // every scene, every root node (:137-142)
     const Json* roots = scenes->arr[s].get("nodes");
-    for (size_t k = 0; roots && k < roots->size(); ++k) visit_node(d, (size_t)roots->arr[k].num, out, 0);
+    for (size_t k = 0; roots && k < roots->size(); ++k) visit_node(d, to_index(roots->arr[k], "root node"), out, 0, visits);
   }
   return out;
 }

@@ -230,3 +230,89 @@ def _recv_exact(conn, k):
             raise RuntimeError("peer closed")
         out += chunk
     return bytes(out)
+
+
+def test_views_in_ordered_tiles_mode(ra, oracle_mod):
+    """A context that must not depend on dispatch order (MIP_CFG_ORDERED_TILES, or after a MIP_ERR_TIMEOUT)
+    runs mip_run_views as one ticketed frame per view: same bytes as the multi-view launch."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=30_011)
+    n = s["n"]
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    views = []
+    for v in range(5):
+        lp = rng.normal(0, 12, 3).astype(np.float32)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        views.append((lp, oracle_mod.project_camera(lp, q.astype(np.float32), aspect=1.3, fovy_degrees=80.0, near=0.2, far=250.0), 7 * v, 1000 * v))
+    with ra.InstancePipeline(max_instances=n, max_meshes=64, ordered_tiles=True) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        bufs = [(torch.full((n, 5), -1, dtype=torch.int32, device=dev), torch.full((8,), -1, dtype=torch.int32, device=dev),
+                 torch.zeros((n + 31) // 32 + 1, dtype=torch.int32, device=dev)) for _ in views]
+        torch.cuda.synchronize()
+        frames = [make_frame(pl, lp, first_instance_base=fib, first_index_base=fxb) for lp, pl, fib, fxb in views]
+        outs = [p.prepare_outputs(draw_cmds=c.data_ptr(), draw_count=sc.data_ptr(), draw_index_total=sc.data_ptr() + 4,
+                                  visible_bitmap=b.data_ptr(), async_=False) for c, sc, b in bufs]
+        for _ in range(2):
+            p.run_views(frames, outs)
+        for (lp, pl, fib, fxb), (cmds, scal, bitmap) in zip(views, bufs):
+            want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], pl, lp, first_instance_base=fib,
+                                  first_index_base=fxb, threads=8, want=("draw_cmds", "visible_bitmap"))
+            count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+            assert count == want["draw_count"] and total == want["draw_index_total"]
+            assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+            assert np.array_equal(bitmap[:(n + 31) // 32].cpu().numpy().view(np.uint32), want["visible_bitmap"])
+
+
+def test_mesh_table_and_geometry_must_agree_before_the_triangle_stage(ra):
+    """The per-triangle kernels gather vertices[vertex_offset + index] and indices[index_offset ..] unchecked, so
+    the host refuses a frame whose mesh table points outside the uploaded geometry (checked once per upload)."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(2, n=500)
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    dev = torch.device("cuda", 0)
+    model = torch.zeros((s["n"], 16), dtype=torch.float32, device=dev)
+    cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+    scal = torch.zeros(8, dtype=torch.int32, device=dev)
+    out = torch.zeros(1 << 22, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    frame = make_frame(s["planes"], s["cam_pos"], pv=ra.scene.default_pv())
+
+    def run(p):
+        p.run_device(frame, model=model.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                     culled_index_buffer=out.data_ptr(), culled_index_capacity=out.numel())
+
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=len(s["meshes"])) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        p.set_geometry(vertices, indices)
+        run(p)                                                # consistent: fine
+        p.set_geometry(vertices, indices[: len(indices) // 2])  # LOD ranges now end outside the index buffer
+        with pytest.raises(ra.MipError) as e:
+            run(p)
+        assert e.value.code == -1 and "outside" in str(e.value)
+        bad = indices.copy()
+        bad[5] = len(vertices)                                # one index one past the vertices
+        p.set_geometry(vertices, bad)
+        with pytest.raises(ra.MipError) as e:
+            run(p)
+        assert e.value.code == -1 and "largest index" in str(e.value)
+        m2 = s["meshes"].copy()
+        m2["vertex_offset"][0] = -1
+        p.set_geometry(vertices, indices)
+        p.set_mesh_table(m2)
+        with pytest.raises(ra.MipError):
+            run(p)
+        p.set_mesh_table(s["meshes"])
+        run(p)                                                # and consistent again
+        # frames that do not ask for the per-triangle stage are not affected by any of this
+        p.set_geometry(vertices, indices[:10])
+        p.run_device(frame, model=model.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr())
