@@ -369,7 +369,26 @@ def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_
     }
 
 
-def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, with_cpu):
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2.0  # 1024 SIMDs x one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md, cycle constants)
+
+
+def triangle_pmc(config, n):
+    """VALU wave-instructions per launch of the triangle kernel from the committed PMC pass, if it was taken from
+    this source of triangle_kernels.hpp."""
+    import glob
+
+    sha = hashlib.sha256(open(os.path.join(ROOT, "renderer_amd", "csrc", "triangle_kernels.hpp"), "rb").read()).hexdigest()[:16]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*triangle*pmc_summary.json"))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("config") == config and doc.get("instances") == n and doc.get("triangle_source_sha") == sha:
+            return doc, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, with_cpu, config=2):
     """generate_work.comp:68-200 for every emitted command of scene `s` (synthetic torus geometry with the mesh
     table's triangle counts): frame = instance kernel + triangle kernel + re-compaction."""
     n = s["n"]
@@ -406,6 +425,18 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
         "note": "instruction-issue/latency bound, not HBM: two mat4*vec4 per vertex without FMA per triangle; geometry is "
                 "L2-resident, HBM traffic is the 12 B per surviving triangle",
     }
+    doc, src = triangle_pmc(config, n)
+    if doc and doc["counters_per_launch"].get("SQ_INSTS_VALU"):
+        valu = doc["counters_per_launch"]["SQ_INSTS_VALU"]
+        kern_ns = list(doc["kernel_ns_under_pmc"].values())[0]
+        row["roofline"] = {
+            "bound": "valu", "kernel": list(doc["kernel_ns_under_pmc"].keys())[0], "achieved": valu / (kern_ns * 1e-9),
+            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instructions/s", "frac": valu / (kern_ns * 1e-9) / VALU_PEAK_WAVE_INSTR_PER_S,
+            "valu_wave_instructions_per_launch": valu, "kernel_ms": kern_ns * 1e-6, "source": src,
+            "valu_busy_fraction": doc.get("fractions_of_wave_cycles", {}).get("SQ_ACTIVE_INST_VALU"),
+            "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; half of the kernel's VALU instructions are "
+                    "packed (v_pk_mul/add_f32: two flops per lane, twice the issue time), so ~0.67 of the SIMD cycles are VALU-busy",
+        }
     if with_cpu:
         import oracle
 

@@ -141,3 +141,25 @@ def test_triangle_cull_reports_a_short_index_buffer(ra, oracle_mod):
             p.run_device(make_frame(s["planes"], s["cam_pos"]), model=buf.data_ptr(), draw_cmds=buf.data_ptr(),
                          draw_count=buf.data_ptr(), culled_index_buffer=buf.data_ptr(), culled_index_capacity=1024)
         assert e.value.code == -6
+
+
+@pytest.mark.parametrize("config,n", [(2, 100_000), (3, 200_000)])
+def test_triangle_cull_at_baseline_sizes(ra, oracle_mod, config, n):
+    """Row f-1 at the sizes the bench runs: BASELINE configs[1] in full (100 k instances, 27 k commands, 213 M
+    triangles in) and the mixed scene at 200 k (114 M triangles). Above 65 536 instances the library selects
+    the one-wave-per-command kernel and the wide re-compaction by itself — nothing is forced here. Every
+    final command, the count and the WHOLE culled index stream (gaps included) against the oracle."""
+    s = ra.scene.make_scene(config, n=n)
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    pv = ra.scene.default_pv()
+    r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=16)
+    capacity = r["draw_index_total"] + 3
+    assert capacity > 300_000_000  # hundreds of millions of indices: the regime of the bench leg
+    want_cmds, want_out, _ = oracle_mod.cull_all_triangles(r, s["pos"], s["mesh_id"], s["meshes"], s["cam_pos"], pv, vertices, indices,
+                                                           out_capacity=capacity, threads=16)
+    got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, frames=1)
+    assert count == len(want_cmds) and total == r["draw_index_total"]
+    assert got_cmds.tobytes() == want_cmds.tobytes()
+    assert np.array_equal(got_out, want_out)
+    survivors = int(want_cmds["indexCount"].astype(np.int64).sum())
+    assert 0.2 < survivors / int(r["draw_cmds"]["indexCount"].astype(np.int64).sum()) < 0.8
