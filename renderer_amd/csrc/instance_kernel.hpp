@@ -237,6 +237,29 @@ __device__ __forceinline__ void instance_fast(const float (&r)[3][3], float px, 
   finish_aabb(lo, hi, o);
 }
 
+// The same eight-corner fold WITHOUT enumerating the corners, bit-exact whenever no intermediate value
+// can overflow or be NaN (separable_safe below). A corner's coordinate is
+//     v = fl(fl(fl(P_x + P_y) + P_z) + m3),   P_x in {fl(m0*min.x), fl(m0*max.x)}, P_y, P_z likewise,
+// and fl(a + b) is monotone non-decreasing in each operand, so the minimum over the eight independent
+// choices is attained at the three smallest products and the maximum at the three largest:
+//     min_corners v = fl(fl(fl(min P_x + min P_y) + min P_z) + m3)      (and the same with max).
+// 18 multiplies, 18 min/max and 18 adds instead of 18 + 60 + 48 — the result the reference's
+// loop over the corners (src/ecs.rs:146-173) produces, up to the sign of a zero.
+__device__ __forceinline__ void instance_separable(const float (&r)[3][3], float px, float py, float pz,
+                                                   float s, const MeshEntry& mb, Instance& o) {
+  model_fast(r, px, py, pz, s, o);
+  float lo[3], hi[3];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    const float x0 = o.m[0 * 3 + rr] * mb.min_x, x1 = o.m[0 * 3 + rr] * mb.max_x;
+    const float y0 = o.m[1 * 3 + rr] * mb.min_y, y1 = o.m[1 * 3 + rr] * mb.max_y;
+    const float z0 = o.m[2 * 3 + rr] * mb.min_z, z1 = o.m[2 * 3 + rr] * mb.max_z;
+    lo[rr] = fminf(x0, x1) + fminf(y0, y1) + fminf(z0, z1) + o.m[9 + rr];
+    hi[rr] = fmaxf(x0, x1) + fmaxf(y0, y1) + fmaxf(z0, z1) + o.m[9 + rr];
+  }
+  finish_aabb(lo, hi, o);
+}
+
 // nalgebra gemv (alpha = 1, beta = 0): column axpys left to right.
 __device__ __forceinline__ void gemv4(const float (&a)[16], const float (&x)[4], float (&y)[4]) {
 #pragma unroll
@@ -489,13 +512,28 @@ __device__ __forceinline__ float finite_magnitude(const float (&r)[3][3], float 
 }
 constexpr float kFiniteLimit = 3.0e38f;
 
+// separable_safe: every product, partial sum and corner coordinate of the world-box computation is finite,
+// so instance_separable is exact. `box_abs` bounds the sum of the magnitudes of the six mesh-box coordinates
+// (the instance's own box, or the largest such sum over the mesh table). |corner| <= sum|M| * box + sum|p| with
+// sum|M| <= sum|R| * |s| (1 + 2^-23); anything non-finite in the inputs makes the bound NaN or inf.
+constexpr float kSeparableLimit = 1.0e37f;
+__device__ __forceinline__ float separable_bound(const float (&r)[3][3], float px, float py, float pz, float sc, float box_abs) {
+  float sum_r = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sum_r += fabsf(r[rr][c]);
+  return sum_r * fabsf(sc) * box_abs + (fabsf(px) + fabsf(py) + fabsf(pz));
+}
+
 // Upload-time census: how many instances of [first, first + count) fail the finite test. The
 // host keeps the total (mip_set_instances*, mip_update_instances); while it is zero the frame is
 // launched as mip_instance_pipeline_kernel<.., .., kGeneral = false>.
 struct CensusArgs {
   const float* pos; const float4* rot; const float* scale;
   uint32_t first, count;
-  uint32_t* out;  // += number of non-finite instances
+  float box_abs;  // largest sum of |box coordinates| over the mesh table
+  uint32_t* out;  // += number of instances that need the kernel with the fall-back paths
 };
 __global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusArgs a) {
   uint32_t bad = 0;
@@ -504,7 +542,9 @@ __global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusAr
     const float4 q = a.rot[i];
     float r[3][3];
     quat_to_rotation(q.x, q.y, q.z, q.w, r);
-    bad += finite_magnitude(r, a.pos[3 * i], a.pos[3 * i + 1], a.pos[3 * i + 2], a.scale[i]) < kFiniteLimit ? 0u : 1u;
+    const float px = a.pos[3 * i], py = a.pos[3 * i + 1], pz = a.pos[3 * i + 2], sc = a.scale[i];
+    const bool ok = finite_magnitude(r, px, py, pz, sc) < kFiniteLimit && separable_bound(r, px, py, pz, sc, a.box_abs) < kSeparableLimit;
+    bad += ok ? 0u : 1u;
   }
   bad = wave_sum(bad);
   if ((threadIdx.x & 63u) == 0u && bad) atomicAdd(a.out, bad);
@@ -639,17 +679,26 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       const float4 lo = b4[0], hi = b4[1];
       mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
       mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
-      // unlike a mesh-table box it may be non-finite: then the literal path is the exact one
-      mag += fabsf(lo.x) + fabsf(lo.y) + fabsf(lo.z) + fabsf(hi.x) + fabsf(hi.y) + fabsf(hi.z);
     }
+    // the instance's own box: a mesh-table box is finite, a box override may be anything
+    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
+    mag += box_abs;
     const bool all_finite = mag < kFiniteLimit;
-    if (__builtin_expect(__any(!all_finite), 0)) {
-      instance_general(r, px, py, pz, sc, mb, inst);
+    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
+    // three tiers, chosen per wave: the separable fold; the corner enumeration (finite inputs whose
+    // intermediate values may overflow); the literal chain (non-finite inputs)
+    if (__builtin_expect(__any(!separable), 0)) {
+      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
+      else instance_fast(r, px, py, pz, sc, mb, inst);
     } else {
-      instance_fast(r, px, py, pz, sc, mb, inst);
+      instance_separable(r, px, py, pz, sc, mb, inst);
     }
   } else {
+#ifdef MIP_EXP_ENUMERATE  // tuning builds only: the corner enumeration in the hot kernel (A/B against the separable fold)
     instance_fast(r, px, py, pz, sc, mb, inst);
+#else
+    instance_separable(r, px, py, pz, sc, mb, inst);  // the upload-time census found every instance separable_safe
+#endif
   }
 
   MIP_STAMP(1);
@@ -861,6 +910,12 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
 #else
   base_count = tile * 64u;
+#ifdef MIP_EXP_FAKE_DELAY  // idle for the time a look-up takes, without its memory traffic
+  {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < MIP_EXP_FAKE_DELAY) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 #endif
   if (lane == 0 && tile == a.n_tiles - 1u) {
     *a.draw_count = base_count + tile_count;

@@ -113,6 +113,7 @@ struct MipContext {
   // upload-time census of instances that fail the kernel's finite test (instance_kernel.hpp,
   // finite_magnitude): while it is zero, frames run the kernel without the literal cold path
   uint64_t nonfinite_instances = 0;
+  float box_abs = 0.f;  // largest sum of |box coordinates| over the mesh table (the census' overflow bound)
   uint32_t* d_census = nullptr;
   uint32_t* h_error = nullptr;  // pinned, device-visible
   uint32_t* d_error = nullptr;  // device alias of h_error
@@ -272,6 +273,7 @@ int32_t census(MipContext* ctx, uint32_t first, uint32_t count, uint32_t* out) {
   mip::CensusArgs c{};
   c.pos = ctx->d_pos; c.rot = ctx->d_rot; c.scale = ctx->d_scale;
   c.first = first; c.count = count; c.out = ctx->d_census;
+  c.box_abs = ctx->box_abs;
   uint32_t blocks = (count + 255u) / 256u;
   if (blocks > 2048u) blocks = 2048u;
   hipLaunchKernelGGL(mip::mip_count_nonfinite_kernel, dim3(blocks), dim3(256), 0, ctx->stream, c);
@@ -576,6 +578,21 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   ctx->have_meshes = true;
   ctx->h_meshes.assign(meshes, meshes + m);
   ctx->geometry_checked = 0;
+  float box_abs = 0.f;
+  for (uint32_t k = 0; k < m; ++k) {
+    float sum = 0.f;
+    for (int a = 0; a < 3; ++a) sum += std::fabs(meshes[k].aabb_min[a]) + std::fabs(meshes[k].aabb_max[a]);
+    if (sum > box_abs) box_abs = sum;
+  }
+  if (box_abs != ctx->box_abs) {  // the census' overflow bound moved: count the resident instances again
+    ctx->box_abs = box_abs;
+    if (ctx->have_instances) {
+      uint32_t bad = 0;
+      if (int32_t rc = census(ctx, 0, ctx->n, &bad)) return rc;
+      if ((bad != 0) != (ctx->nonfinite_instances != 0)) ctx->graph_generation++;
+      ctx->nonfinite_instances = bad;
+    }
+  }
   return MIP_OK;
 }
 

@@ -109,7 +109,9 @@ def test_finite_census_picks_the_kernel(ra, oracle_mod):
         assert p.timings()["general_launches"] == 0
         for what, col, row, val in (("nan position", "pos", 12_345, [np.nan, 1.0, 2.0]),
                                     ("inf scale", "scale", 77, np.inf),
-                                    ("huge quaternion", "rot", 29_999, [3e19, 3e19, 0.0, 1.0])):  # w*w, i*i overflow
+                                    ("huge quaternion", "rot", 29_999, [3e19, 3e19, 0.0, 1.0]),  # w*w, i*i overflow
+                                    # finite inputs whose corner arithmetic overflows: the corner-enumerating tier
+                                    ("huge scale", "scale", 123, 3e37), ("far position", "pos", 4_000, [2e37, -3e37, 1e37])):
             old = s[col][row].copy()
             s[col][row] = val
             kw = {"pos": "pos_xyz", "rot": "rot_ijkw", "scale": "scale"}[col]
