@@ -104,6 +104,9 @@ struct KernelArgs {
   float planes[24];
   float cam[3];
   const uint32_t* frame_ring;   // this launch's FrameWords, or null
+#ifdef MIP_EXP_FAKE_DELAY
+  uint32_t delay_first, delay_last;  // tuning builds: tiles in [first, last) idle in place of the look-up
+#endif
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
   uint32_t debug_skip_publish_tile;  // diagnostic build only: tile index + 1 that never publishes (0 = off)
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 #else
   base_count = tile * 64u;
 #ifdef MIP_EXP_FAKE_DELAY  // idle for the time a look-up takes, without its memory traffic
-  {
+  if (tile >= a.delay_first && tile < a.delay_last) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < MIP_EXP_FAKE_DELAY) __builtin_amdgcn_s_sleep(8);
   }

@@ -252,13 +252,16 @@ FrameKernel pick_order(bool ticketed, int order) {
   return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1>
                     : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 3>;
 }
-FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override) {
+FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool tlas, uint32_t* grid) {
+  const uint32_t n_tiles = tiles_for(ctx->n);
+  *grid = n_tiles;
   // order (instance_kernel.hpp): commands-first while the launch is less than two generations of
   // workgroups (8 per CU: every tile is ramp or tail), stores-first once there is a steady state.
   // Measured cross-over on MI355X: equal at 0.7-1 M instances, order 3 ahead below (200 k: 7.7 vs
   // 8.4 us), order 1 ahead above (1.25 M: 24.3 vs 25.3 us; 10 M: 191 vs 240 us).
-  int order = tiles_for(ctx->n) <= (uint32_t)ctx->cu_count * 16u ? 3 : 1;
+  int order = n_tiles <= (uint32_t)ctx->cu_count * 16u ? 3 : 1;
   if (ctx->force_order) order = ctx->force_order;
+  (void)tlas;
   if (box_override) return pick_order<true, true>(ctx->ordered_tiles, order);
   if (ctx->nonfinite_instances != 0 || ctx->force_general) return pick_order<false, true>(ctx->ordered_tiles, order);
   return pick_order<false, false>(ctx->ordered_tiles, order);
@@ -313,6 +316,10 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
   std::memcpy(a.cam, frame->cam_pos, sizeof a.cam);
   a.n_tiles = tiles_for(n);
+#ifdef MIP_EXP_FAKE_DELAY
+  a.delay_first = std::getenv("MIP_TUNE_DELAY_FIRST") ? (uint32_t)std::atoi(std::getenv("MIP_TUNE_DELAY_FIRST")) : 0u;
+  a.delay_last = std::getenv("MIP_TUNE_DELAY_LAST") ? (uint32_t)std::atoi(std::getenv("MIP_TUNE_DELAY_LAST")) : 0xffffffffu;
+#endif
   a.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
 #ifdef MIP_DEBUG_STAMPS
   a.stamps = ctx->d_stamps;
@@ -786,8 +793,9 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     {
       void* params[1] = {&a};
       if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
-      MIP_HIP(ctx, hipLaunchKernel((const void*)select_frame_kernel(ctx, skinned), dim3(a.n_tiles), dim3(mip::kTile), params,
-                                   ctx->lds_pad, stream));
+      uint32_t grid = 0;
+      const FrameKernel kernel = select_frame_kernel(ctx, skinned, a.tlas_instances != nullptr, &grid);
+      MIP_HIP(ctx, hipLaunchKernel((const void*)kernel, dim3(grid), dim3(mip::kTile), params, ctx->lds_pad, stream));
     }
     if (triangles) {
       mip::TriangleArgs t{};
@@ -987,8 +995,9 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           a.epoch = base + 1 + j;
           void* params[1] = {&a};
           hipKernelNodeParams kp{};
-          kp.func = (void*)select_frame_kernel(ctx, false);
-          kp.gridDim = dim3(a.n_tiles);
+          uint32_t grid = 0;
+          kp.func = (void*)select_frame_kernel(ctx, false, a.tlas_instances != nullptr, &grid);
+          kp.gridDim = dim3(grid);
           kp.blockDim = dim3(mip::kTile);
           kp.sharedMemBytes = ctx->lds_pad;
           kp.kernelParams = params;
