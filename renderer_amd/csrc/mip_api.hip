@@ -255,11 +255,12 @@ FrameKernel pick_order(bool ticketed, int order) {
 FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool tlas, uint32_t* grid) {
   const uint32_t n_tiles = tiles_for(ctx->n);
   *grid = n_tiles;
-  // order (instance_kernel.hpp): commands-first while the launch is less than two generations of
+  // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of
   // workgroups (8 per CU: every tile is ramp or tail), stores-first once there is a steady state.
-  // Measured cross-over on MI355X: equal at 0.7-1 M instances, order 3 ahead below (200 k: 7.7 vs
-  // 8.4 us), order 1 ahead above (1.25 M: 24.3 vs 25.3 us; 10 M: 191 vs 240 us).
-  int order = n_tiles <= (uint32_t)ctx->cu_count * 16u ? 3 : 1;
+  // Measured on MI355X (profiles/r02_order*.txt, r02_next_generation_prefetch_ab.txt): order 3 ahead below
+  // ~0.8 M instances (200 k: 7.7 vs 8.4 us; 700 k: 14.1 vs 14.3), order 1 ahead from ~1 M (1 M: 19.7 vs 20.2;
+  // 1.25 M: 24.0 vs 24.9; 10 M: 191 vs 240 us).
+  int order = n_tiles <= (uint32_t)ctx->cu_count * 14u ? 3 : 1;
   if (ctx->force_order) order = ctx->force_order;
   (void)tlas;
   if (box_override) return pick_order<true, true>(ctx->ordered_tiles, order);
