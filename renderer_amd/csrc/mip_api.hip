@@ -226,8 +226,16 @@ const RcclApi* rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // The collective library is a seam: anything that exports ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy,
+    // ncclAllGather (and optionally ncclGetErrorString) will do. MIP_COMM_LIBRARY names it; the default is RCCL.
+    // (tests/fake_ccl is a shared-memory double with which the native sharded frame runs with several ranks on one GPU.)
+    void* h = nullptr;
+    if (const char* env = std::getenv("MIP_COMM_LIBRARY")) {
+      h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    }
     if (h) {
       api.get_unique_id = (decltype(api.get_unique_id))dlsym(h, "ncclGetUniqueId");
       api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(h, "ncclCommInitRank");

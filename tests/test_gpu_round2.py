@@ -318,3 +318,85 @@ def test_mesh_table_and_geometry_must_agree_before_the_triangle_stage(ra):
         # frames that do not ask for the per-triangle stage are not affected by any of this
         p.set_geometry(vertices, indices[:10])
         p.run_device(frame, model=model.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr())
+
+
+_SHARDED_RANK = r'''
+import os, sys
+root, rank, world, n_global, id_path, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import time
+import numpy as np, torch
+import renderer_amd, oracle
+from renderer_amd import scene
+from renderer_amd.pipeline import make_frame
+from renderer_amd.sharded import shard_range
+
+full = scene.make_scene(3, n=n_global)
+lo, hi = shard_range(n_global, world, rank)
+s = scene.make_scene(3, n=hi - lo, first=lo)
+if rank == 0:
+    uid = renderer_amd.InstancePipeline.comm_unique_id()
+    open(id_path + ".tmp", "wb").write(uid); os.rename(id_path + ".tmp", id_path)
+else:
+    t0 = time.time()
+    while not os.path.exists(id_path):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    uid = open(id_path, "rb").read()
+dev = torch.device("cuda", 0)
+cam_b = np.array([0.0, 1.0, -40.0], np.float32)            # sees more than the default camera
+planes_b = oracle.project_camera(cam_b, (0.0, 0.0, 0.0, 1.0))
+want_a = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], full["planes"], full["cam_pos"], want=("draw_cmds", "visible_bitmap"))
+want_b = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], planes_b, cam_b, want=("draw_cmds",))
+with renderer_amd.InstancePipeline(max_instances=hi - lo, max_meshes=64) as p:
+    p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    p.comm_init(uid, rank, world)
+    merged = torch.zeros((n_global, 5), dtype=torch.int32, device=dev)
+    count = torch.zeros(2, dtype=torch.int32, device=dev)
+    bitmap = torch.zeros((hi - lo + 31) // 32, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    frame_a = make_frame(full["planes"], full["cam_pos"], first_instance_base=lo)
+    frame_b = make_frame(planes_b, cam_b, first_instance_base=lo)
+    def check(want, what):
+        total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
+        assert total == want["draw_count"] and index_total == want["draw_index_total"], (what, total, want["draw_count"])
+        assert merged[:total].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
+    p.run_sharded(frame_a, merged.data_ptr(), count.data_ptr(), visible_bitmap=bitmap.data_ptr())           # full capacity
+    check(want_a, "A full")
+    vis_local = np.unpackbits(bitmap.cpu().numpy().view(np.uint8), bitorder="little")[: hi - lo]
+    assert np.array_equal(vis_local, np.unpackbits(want_a["visible_bitmap"].view(np.uint8), bitorder="little")[lo:hi])
+    cap = int(max(1, want_a["draw_count"] // world * 1.1))    # fits camera A's shards, not camera B's
+    p.run_sharded(frame_a, merged.data_ptr(), count.data_ptr(), chunk_capacity=cap)
+    check(want_a, "A tightened")
+    assert p.timings()["sharded_retries"] == 0
+    for async_ in (False, True):                              # the camera moves: every rank sees the overflow and repairs it together
+        merged.zero_(); torch.cuda.synchronize()
+        before = p.timings()["sharded_retries"]
+        p.run_sharded(frame_b, merged.data_ptr(), count.data_ptr(), chunk_capacity=cap, async_=async_)
+        if async_:
+            p.wait()
+        check(want_b, "B repaired")
+        assert p.timings()["sharded_retries"] == before + 1
+    p.run_sharded(frame_a, merged.data_ptr(), count.data_ptr(), chunk_capacity=cap)
+    check(want_a, "A again")
+    p.comm_destroy()
+open(out_path, "w").write("ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_sharded_frame_with_several_ranks_on_one_gpu(ra, tmp_path, world):
+    """mip_comm_init / mip_run_sharded with world size 2 and 3: one process per rank, all on this box's one GPU,
+    the collective library replaced through the MIP_COMM_LIBRARY seam by tests/fake_ccl (a shared-memory double of
+    the five nccl* entry points). The library's own sequence — shard kernel -> all-gather -> merge — and its
+    collective overflow repair run unchanged; every rank must hold the unsharded oracle's list."""
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "fake_ccl", "fake_rccl.cpp"), "-o", fake, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    env = dict(os.environ, MIP_COMM_LIBRARY=fake)
+    id_path = str(tmp_path / "uid")
+    procs = [subprocess.Popen([sys.executable, "-c", _SHARDED_RANK, ROOT, str(r), str(world), "90001", id_path, str(tmp_path / f"ok{r}")],
+                              env=env, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = [p.communicate(timeout=300)[1] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and os.path.exists(tmp_path / f"ok{r}"), f"rank {r}:\n{errs[r][-3000:]}"
