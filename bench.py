@@ -273,7 +273,7 @@ def frames_in_flight_leg(torch, renderer_amd, make_frame, s, device, local_rank,
     return {"instances": n, "frames_in_flight": frames, "steps_per_sample": steps, "ms_per_step": ms, "instances_per_s": n / (ms * 1e-3),
             "algorithmic_GBps": b / (ms * 1e-3) / 1e9, "frac_of_8000": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "host_loop": (f"compiled (mip_run_many): {replayed} of {7 * steps} timed frames replayed as hipGraphs, the rest direct launches"
-                          if replayed else "compiled (mip_run_many): direct launches (fewer steps than one replay round of 64)"),
+                          if replayed else "compiled (mip_run_many): direct launches (no replay round of 64 frames fits the steps, or launch graphs are off)"),
             "note": "wall clock around the call incl. the final wait; overlapping frames: a throughput figure, not the §8(d) metric"}
 
 
