@@ -433,9 +433,11 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
             "bound": "valu", "kernel": list(doc["kernel_ns_under_pmc"].keys())[0], "achieved": valu / (kern_ns * 1e-9),
             "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instructions/s", "frac": valu / (kern_ns * 1e-9) / VALU_PEAK_WAVE_INSTR_PER_S,
             "valu_wave_instructions_per_launch": valu, "kernel_ms": kern_ns * 1e-6, "source": src,
-            "valu_busy_fraction": doc.get("fractions_of_wave_cycles", {}).get("SQ_ACTIVE_INST_VALU"),
-            "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; half of the kernel's VALU instructions are "
-                    "packed (v_pk_mul/add_f32: two flops per lane, twice the issue time), so ~0.67 of the SIMD cycles are VALU-busy",
+            "simd_valu_busy_fraction": (doc["counters_per_launch"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * doc["counters_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0)
+                                        if doc["counters_per_launch"].get("SQ_ACTIVE_INST_VALU") and doc["counters_per_launch"].get("GRBM_GUI_ACTIVE") else None),
+            "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; peak = one wave64 VALU instruction per "
+                    "2 cycles per SIMD. Half of this kernel's VALU instructions are packed (v_pk_mul/add_f32: two flops per lane, twice "
+                    "the issue time): simd_valu_busy_fraction = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles)",
         }
     if with_cpu:
         import oracle
