@@ -411,7 +411,13 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
     __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;  // 0.5 s of the 100 MHz realtime counter
+// A wait gives up (MIP_ERR_TIMEOUT) only when BOTH bounds are exceeded: 0.5 s of the 100 MHz realtime counter AND
+// 2^18 polls by this wave (each a memory round trip + s_sleep, >= ~1 us: at least a quarter of a second of RUNNING
+// time). The realtime bound alone expired spuriously when several processes shared the GPU and the hardware
+// scheduler kept this process's queue off the chip for long stretches (seen with 2-3 ranks of the bench on one
+// GPU over gloo): a wave that is not running is not stuck.
+constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;
+constexpr uint32_t kSpinMinPolls = 1u << 18;
 constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
 
 // Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`:
@@ -444,7 +450,7 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
   const unsigned long long* e2 = &a.start1[2 * (size_t)g_lo];
 
   bool ready0 = !v0, ready1 = !v1, ready2 = !v2;
-  uint32_t c = 0, s = 0;
+  uint32_t c = 0, s = 0, polls = 0;
   for (;;) {
     if (!ready0) {
       const unsigned long long g = status_load(e0);
@@ -476,7 +482,7 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
     if (__all(all)) break;
-    if (__builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
+    if (++polls > kSpinMinPolls && __builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
       ok = false;
       break;
     }
