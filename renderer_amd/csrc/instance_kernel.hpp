@@ -47,7 +47,6 @@ constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per w
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
-constexpr uint32_t kMeshCacheEntries = 128;  // mesh tables up to this size are read through LDS (32 B each, inside the command area)
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
 // len0 = index_len[0]; len1 = index_len[1] if n_lods > 1 else index_len[0]
@@ -95,7 +94,7 @@ struct KernelArgs {
   uint32_t n_tiles;
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
-  uint32_t n_meshes;            // mesh-table entries (tables of <= kMeshCacheEntries are staged in LDS)
+  uint32_t n_meshes;            // mesh-table entries
   // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
   // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
   // without re-recording: the host refreshes the ring with one copy per replay
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];    // rows 0..2 of every matrix
   __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3 + mesh id
   // the tile's commands, in order: order 1 reuses the staging area of waves 1-3 once they have stored;
-  // order 3 has an area of its own (which holds the mesh-table cache before that)
+  // order 3 has an area of its own
   __shared__ __attribute__((aligned(16))) uint32_t s_cmd_own[kOrder == 3 ? kTile * kCmdLdsWords : 4];
   static_assert((kTile - 64) * 12 >= kTile * kCmdLdsWords, "commands must fit the staging area of waves 1-3");
   uint32_t* const s_cmd = kOrder == 1 ? reinterpret_cast<uint32_t*>(&s_mat[64 * 12]) : s_cmd_own;
@@ -644,17 +643,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const float4 q = a.rot[il];
   const float sc = a.scale[il];
   const uint32_t mesh = a.mesh_id[il];
-  // Small mesh tables are staged in LDS (inside the command area, which is not written before every
-  // wave has finished its arithmetic): the box then costs an LDS read after the mesh id arrives
-  // instead of a second, dependent trip through the vector memory queue.
-#ifdef MIP_EXP_MESH_CACHE  // measured: no gain at 100 k / 1 M / 10 M (the gather is not what the publish waits for)
-  const bool mesh_cached = kOrder == 3 && want_cmds && a.n_meshes <= kMeshCacheEntries;
-#else
-  const bool mesh_cached = false;
-#endif
-  static_assert(kMeshCacheEntries * 32u <= kTile * kCmdLdsWords * 4u, "the mesh cache lives inside the command area");
-  if (mesh_cached && tid < 2u * a.n_meshes)
-    reinterpret_cast<float4*>(s_cmd)[tid] = reinterpret_cast<const float4*>(a.meshes)[tid];
   if constexpr (!kTicketedTiles) {
     // the LDS word the waves add their aggregates to; the barrier does not wait for the instance
     // loads above, and every wave of the workgroup has only just started
@@ -662,17 +650,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       if (tid == 0) s_tile_agg = 0ull;
       __syncthreads();
     }
-  } else {
-    if (mesh_cached) __syncthreads();
   }
-  float4 mb0, mb1;
-  if (mesh_cached) {
-    mb0 = reinterpret_cast<const float4*>(s_cmd)[2u * mesh];
-    mb1 = reinterpret_cast<const float4*>(s_cmd)[2u * mesh + 1u];
-  } else {
-    mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
-    mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
-  }
+  // (a copy of small mesh tables in LDS was measured: no gain — profiles/r02_lds_pad_occupancy_and_mesh_cache_ab.txt)
+  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
+  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
   MeshEntry mb;
   mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
   mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
@@ -703,11 +684,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       instance_separable(r, px, py, pz, sc, mb, inst);
     }
   } else {
-#ifdef MIP_EXP_ENUMERATE  // tuning builds only: the corner enumeration in the hot kernel (A/B against the separable fold)
-    instance_fast(r, px, py, pz, sc, mb, inst);
-#else
     instance_separable(r, px, py, pz, sc, mb, inst);  // the upload-time census found every instance separable_safe
-#endif
   }
 
   MIP_STAMP(1);
@@ -901,13 +878,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // path is saturated. Wave 0 issues no bulk store: it spends that time on the one memory round trip
   // of the tile's prefix and then copies the commands out.
   if (wave != 0) {
-#ifdef MIP_EXP_STRIDED_PIECES
-    for (uint32_t p = wave - 1u; p < 16u; p += kWaves - 1u) store_piece(p);
-#else
-    // contiguous runs (6 + 5 + 5 KiB): consecutive store instructions of a wave stay in one DRAM page
+    // contiguous runs of 6 + 5 + 5 KiB
     const uint32_t p0 = wave == 1u ? 0u : (wave == 2u ? 6u : 11u), p1 = wave == 1u ? 6u : (wave == 2u ? 11u : 16u);
     for (uint32_t p = p0; p < p1; ++p) store_piece(p);
-#endif
     if (wave == 1) store_bitmap();
     store_aabb();
     return;

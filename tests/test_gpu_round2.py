@@ -400,3 +400,51 @@ def test_native_sharded_frame_with_several_ranks_on_one_gpu(ra, tmp_path, world)
     errs = [p.communicate(timeout=300)[1] for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0 and os.path.exists(tmp_path / f"ok{r}"), f"rank {r}:\n{errs[r][-3000:]}"
+
+
+def test_recorded_graphs_follow_the_census(ra, oracle_mod):
+    """Recorded launch graphs name a kernel instantiation. When a partial update makes the first instance non-finite
+    (or the last one finite again) the choice changes, and mip_run_many has to re-record instead of replaying the
+    kernel without the fall-back arithmetic."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(3, n=40_000)
+    n = s["n"]
+    dev = torch.device("cuda", 0)
+    with ra.InstancePipeline(max_instances=n, max_meshes=64, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in range(2):
+            cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+            sets.append((cmds, scal, model, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                                                                draw_index_total=scal.data_ptr() + 4, model=model.data_ptr())))
+        torch.cuda.synchronize()
+        frame = make_frame(s["planes"], s["cam_pos"])
+        outs = [x[3] for x in sets]
+
+        def check(what):
+            want = run_oracle(oracle_mod, s, want=("draw_cmds", "model"))
+            for cmds, scal, model, _ in sets:
+                c = int(scal[0].item())
+                assert c == want["draw_count"] and cmds[:c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
+                got = model.cpu().numpy()
+                assert bool(np.all((got == want["model"]) | (np.isnan(got) & np.isnan(want["model"])))), what
+
+        p.run_many(frame, outs, 128); p.wait()
+        check("finite")
+        assert p.timings()["graph_records"] == 1 and p.timings()["general_launches"] == 0
+        s["pos"][123] = [np.nan, 0.0, 1.0]
+        p.update_instances(123, pos_xyz=s["pos"][123:124])
+        p.run_many(frame, outs, 128); p.wait()
+        check("one NaN")
+        assert p.timings()["graph_records"] == 2
+        s["pos"][123] = [1.0, 2.0, 3.0]
+        p.update_instances(123, pos_xyz=s["pos"][123:124])
+        p.run_many(frame, outs, 128); p.wait()
+        check("finite again")
+        assert p.timings()["graph_records"] == 3
