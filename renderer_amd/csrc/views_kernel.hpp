@@ -81,16 +81,17 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
   float r[3][3];
   quat_to_rotation(q.x, q.y, q.z, q.w, r);
-  float mag = fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(sc);
-#pragma unroll
-  for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mag += fabsf(r[rr][c]);
+  // the three arithmetic tiers of the instance kernel, chosen per wave (instance_kernel.hpp)
+  const float mag = finite_magnitude(r, px, py, pz, sc);
+  const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
+  const bool all_finite = mag < kFiniteLimit;
+  const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
   Instance inst;
-  if (__builtin_expect(__any(!(mag < 3.0e38f)), 0)) {
-    instance_general(r, px, py, pz, sc, mb, inst);
+  if (__builtin_expect(__any(!separable), 0)) {
+    if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
+    else instance_fast(r, px, py, pz, sc, mb, inst);
   } else {
-    instance_fast(r, px, py, pz, sc, mb, inst);
+    instance_separable(r, px, py, pz, sc, mb, inst);
   }
 
   // ---- per view: frustum test, LOD, wave-level compaction offsets ----
