@@ -43,6 +43,8 @@ struct MipContext {
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
+    unsigned long long* d_part_status = nullptr;  //                small frames: one granule per (command, part)
+    uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
     // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
     // refreshed before every replay from one of two pinned staging halves
@@ -110,6 +112,10 @@ struct MipContext {
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
+  uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
+                                   // measured (DamagedHelmet entry, frame time parts / workgroup-per-command): 30 instances 14 / 24 us,
+                                   // 200: 16 / 25, 1000: 41 / 47, 2000: 67 / 64, 4000: 113 / 83
+  uint32_t max_lod_tris = 0;       // largest triangle count of LOD 0 / LOD 1 over the mesh table
   // upload-time census of instances that fail the kernel's finite test (instance_kernel.hpp,
   // finite_magnitude): while it is zero, frames run the kernel without the literal cold path
   uint64_t nonfinite_instances = 0;
@@ -441,6 +447,7 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_tmp_cmds);
     (void)hipFree(sl.d_tmp_src);
     (void)hipFree(sl.d_tmp_blocks);
+    (void)hipFree(sl.d_part_status);
     (void)hipFree(sl.d_skin_box);
     (void)hipFree(sl.d_frame_ring);
     if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
@@ -535,6 +542,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
       if (v == 256u || v == 512u || v == 1024u) ctx->tri_block_threads = v;
     }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDERED_TILES")) ctx->ordered_tiles = std::atoi(env) != 0;
     if (const char* env = std::getenv("MIP_TUNE_ORDER")) {
       const int v = std::atoi(env);
@@ -594,6 +602,10 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   ctx->have_meshes = true;
   ctx->h_meshes.assign(meshes, meshes + m);
   ctx->geometry_checked = 0;
+  ctx->max_lod_tris = 0;
+  for (uint32_t k = 0; k < m; ++k)
+    for (uint32_t l = 0; l < meshes[k].n_lods && l < 2u; ++l)
+      if (meshes[k].index_len[l] / 3u > ctx->max_lod_tris) ctx->max_lod_tris = meshes[k].index_len[l] / 3u;
   float box_abs = 0.f;
   for (uint32_t k = 0; k < m; ++k) {
     float sum = 0.f;
@@ -823,7 +835,29 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
       // The command count lives on the device; the instance count bounds it. Small frames: one
       // 1024-thread workgroup per command; large frames: one wave per command (no barriers).
-      if (n <= ctx->tri_block_max) {
+      const bool parts = ctx->tri_parts_max && n <= ctx->tri_parts_max && !ctx->tri_block_threads &&
+                         ctx->max_lod_tris <= mip::kTriParts * 256u * mip::kTriPartMaxT;
+      if (parts) {
+        // small frames: 16 parts per command, handed out in order by a ticket counter (triangle_kernels.hpp)
+        const size_t cap_cmds = ctx->max_instances < ctx->tri_parts_max ? (ctx->max_instances ? ctx->max_instances : 1) : ctx->tri_parts_max;
+        if (!sl.d_part_status) {
+          MIP_HIP(ctx, hipMalloc(&sl.d_part_status, cap_cmds * mip::kTriParts * 8));
+          MIP_HIP(ctx, hipMemsetAsync(sl.d_part_status, 0, cap_cmds * mip::kTriParts * 8, stream));
+          sl.tri_epoch = 0;
+        }
+        if (sl.tri_epoch == 0xffffffffu) {  // tag wrap: start over on a cleared array
+          MIP_HIP(ctx, hipMemsetAsync(sl.d_part_status, 0, cap_cmds * mip::kTriParts * 8, stream));
+          sl.tri_epoch = 0;
+        }
+        mip::TrianglePartsArgs pa{};
+        pa.t = t;
+        pa.part_status = sl.d_part_status;
+        pa.epoch = ++sl.tri_epoch;
+        uint32_t blocks = n * mip::kTriParts;
+        const uint32_t max_blocks = (uint32_t)ctx->cu_count * 4u;  // resident as a whole at this kernel's 121 VGPRs (4 waves per SIMD)
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL(mip::mip_triangle_cull_parts_kernel, dim3(blocks), dim3(256), 0, stream, pa);
+      } else if (n <= ctx->tri_block_max) {
         // workgroup size: the register budget allows 16 waves per CU, so 1024 / 512 / 256 threads = 1 / 2 / 4
         // workgroups per CU; smaller workgroups wait less at the per-step barrier, larger ones finish a
         // lone command sooner

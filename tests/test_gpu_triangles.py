@@ -65,12 +65,16 @@ def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     assert 0 < survivors < int(r["draw_cmds"]["indexCount"].astype(np.int64).sum())  # something was culled, something survived
 
 
-@pytest.mark.parametrize("mode", ["wave", "block256", "block512", "block1024"])
+@pytest.mark.parametrize("mode", ["wave", "block256", "block512", "block1024", "parts"])
 def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
-    """The library picks wave-per-command or a 256/512/1024-thread workgroup per command by instance count;
+    """The library picks sixteen parts per command, a 256/512/1024-thread workgroup per command or one wave per
+    command by instance count;
     here each variant is forced (tuning variables, read by mip_create) onto the same mixed scene."""
     if mode == "wave":
         monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+        monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "0")
+    elif mode == "parts":  # 16 work items per command (small frames), forced onto this larger frame
+        monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "100000000")
     else:
         monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "100000000")
         monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_THREADS", mode[5:])
