@@ -34,6 +34,9 @@ doc=dict(kernel_source_sha=sha.hexdigest()[:16], config=$CFG, launches_per_pass=
 if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"]:
     wc=m["SQ_WAVE_CYCLES"]
     doc["fractions_of_wave_cycles"]={k: m[k]/wc for k in ("SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_WAIT_INST_LDS") if k in m}
+if m.get("SQ_WAVE_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES counts quad-cycles summed over waves
+    doc["mean_resident_waves_per_simd"]=m["SQ_WAVE_CYCLES"]*4.0/((m["GRBM_GUI_ACTIVE"]/8.0)*1024.0)
 if "SQ_WAVES" in m and m.get("SQ_WAVES"):
     doc["valu_instructions_per_wave"]=m.get("SQ_INSTS_VALU",0)/m["SQ_WAVES"]
 json.dump(doc, open(f"{out}/sq_summary.json","w"), indent=1)
