@@ -168,7 +168,11 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
       const uint32_t qd = lane + 64u * i;
       if (qd < quads) {
         const float* c = wave_lds + (qd >> 2) * 12u + (qd & 3u) * 3u;
+#ifdef MIP_EXP_SKIN_NO_NT
         out[qd] = make_float4(c[0], c[1], c[2], (qd & 3u) == 3u ? 1.0f : 0.0f);
+#else
+        store_stream16(&out[qd], make_float4(c[0], c[1], c[2], (qd & 3u) == 3u ? 1.0f : 0.0f));  // written once, 1 KiB per instruction
+#endif
       }
     }
   }
