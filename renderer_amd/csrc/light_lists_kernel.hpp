@@ -72,8 +72,14 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
     uint32_t* dst = a.out + ((size_t)l * a.n + first) * kCmdWords;
     if constexpr (kAligned16) {
       // n % 4 == 0: every tile row starts on a 16-B boundary and in_tile % 4 == 0
-      for (uint32_t q = tid; q * 4u < words; q += kTile)
-        reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(row)[q];
+      for (uint32_t q = tid; q * 4u < words; q += kTile) {
+        const uint4 v = reinterpret_cast<const uint4*>(row)[q];
+#ifdef MIP_EXP_LIGHT_NO_NT
+        reinterpret_cast<uint4*>(dst)[q] = v;
+#else  // written once, lane-contiguous 16-B stores: non-temporal, as the matrices of the instance kernel
+        store_stream16(reinterpret_cast<float4*>(dst) + q, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+#endif
+      }
     } else {
       for (uint32_t w = tid; w < words; w += kTile) dst[w] = row[w];
     }
