@@ -806,7 +806,12 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       tile_sum += ws;
     }
     MIP_STAMP(2);
-    if (wave != 0) own_stores();
+    if (wave != 0) {  // waves 1-3 store all sixteen pieces (wave 0's too): wave 0 has nothing left to store after its copy-out
+      const uint32_t p0 = wave == 1u ? 0u : (wave == 2u ? 6u : 11u), p1 = wave == 1u ? 6u : (wave == 2u ? 11u : 16u);
+      for (uint32_t p = p0; p < p1; ++p) store_piece(p);
+      if (wave == 1) store_bitmap();
+      store_aabb();
+    }
     __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
     if (keep) {
       const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
@@ -835,7 +840,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     if (a.src_index_offset)
       for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
-    own_stores();
+    store_aabb();
     MIP_STAMP(5);
     return;
   }
