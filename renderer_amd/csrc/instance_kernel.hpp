@@ -410,28 +410,6 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
     __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#ifdef MIP_EXP_SCALAR_PUBLISH
-// The same publication through the scalar memory path (s_store / s_atomic_add): it does not queue behind the
-// vector stores of the other workgroups of this CU. Called by a whole wave with wave-uniform arguments.
-template <class A>
-__device__ __forceinline__ void publish_aggregate_scalar(const A& a, uint32_t tile, uint32_t count, uint32_t sum) {
-  typedef unsigned int pub_u32x2 __attribute__((ext_vector_type(2)));
-  pub_u32x2 g, add, zero;
-  g[0] = (a.epoch << kTileCountBits) | count; g[1] = sum;
-  add[0] = (1u << kAccCountBits) | count; add[1] = sum;
-  zero[0] = 0u; zero[1] = 0u;
-  const uint32_t group = tile >> a.group_shift;
-  const uint32_t parity = a.epoch & 1u;
-  unsigned long long* p0 = &a.status0[tile];
-  unsigned long long* p1 = &a.acc1[((size_t)parity * a.groups_cap + group) * kAccStrideWords];
-  unsigned long long* p2 = &a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords];
-  asm volatile("s_store_dwordx2 %0, %1, 0x0 glc" :: "s"(g), "s"(p0) : "memory");
-  asm volatile("s_atomic_add_x2 %0, %1, 0x0" :: "s"(add), "s"(p1) : "memory");
-  if ((tile & ((1u << a.group_shift) - 1u)) == 0u) asm volatile("s_store_dwordx2 %0, %1, 0x0 glc" :: "s"(zero), "s"(p2) : "memory");
-  asm volatile("s_dcache_wb\n s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-#endif
-
 // A wait gives up (MIP_ERR_TIMEOUT) only when BOTH bounds are exceeded: 0.5 s of the 100 MHz realtime counter AND
 // 2^18 polls by this wave (each a memory round trip + s_sleep, >= ~1 us: at least a quarter of a second of RUNNING
 // time). The realtime bound alone expired spuriously when several processes shared the GPU and the hardware
@@ -470,59 +448,35 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
   const bool v2 = g_lo > 0u && lane == 0u;
   const unsigned long long* e2 = &a.start1[2 * (size_t)g_lo];
 
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE3)
-  {  // how long one gather of each level takes on its own, serialised (values discarded)
-    const unsigned long long g0 = status_load(e0);
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(g0) : "memory");
-    const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long g1 = status_load(e1);
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(g1) : "memory");
-    const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
-    if (a.stamps && lane == 0) {
-      a.stamps[(size_t)blockIdx.x * 8 + 6] = ta - t_start;
-      a.stamps[(size_t)blockIdx.x * 8 + 7] = tb - ta;
-    }
-  }
-#endif
   bool ready0 = !v0, ready1 = !v1, ready2 = !v2;
   uint32_t c = 0, s = 0, polls = 0;
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE2)
-  bool probe_done0 = false, probe_done1 = false;
-  unsigned long long probe_last0 = 0, probe_last1 = 0;
-#endif
   for (;;) {
-    // All four words in flight before the first is looked at: one memory round trip per poll (≈0.5 µs behind
-    // streaming stores), not one per level. Lanes that are already ready, or have nothing to read at a level,
-    // read the tile's own granule and ignore it (re-reading accumulators that are still receiving adds is not free).
-    unsigned long long g = 0, w = 0, pc = 0, ps = 0;
-#ifdef MIP_EXP_POLL_IDLE
-    const unsigned long long* idle = &a.status0[tile];
-    g = status_load(ready0 ? idle : e0); w = status_load(ready1 ? idle : e1);
-    pc = status_load(ready2 ? idle : e2); ps = status_load(ready2 ? idle : e2 + 1);
-#else
-    if (!ready0) g = status_load(e0);  // exec-masked: a lane that is done issues nothing
-    if (!ready1) w = status_load(e1);
-    if (!ready2) { pc = status_load(e2); ps = status_load(e2 + 1); }
-#endif
-    const bool hit0 = !ready0 && (((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch;
-    const bool hit1 = !ready1 && ((uint32_t)w >> kAccCountBits) == per_group;  // every tile of that group has added
-    const bool hit2 = !ready2 && (uint32_t)(pc >> 32) == a.epoch && (uint32_t)(ps >> 32) == a.epoch;
-    c += (hit0 ? (uint32_t)g & ((1u << kTileCountBits) - 1u) : 0u) + (hit1 ? (uint32_t)w & ((1u << kAccCountBits) - 1u) : 0u) + (hit2 ? (uint32_t)pc : 0u);
-    s += (hit0 ? (uint32_t)(g >> 32) : 0u) + (hit1 ? (uint32_t)(w >> 32) : 0u) + (hit2 ? (uint32_t)ps : 0u);
-    ready0 = ready0 || hit0;
-    ready1 = ready1 || hit1;
-    ready2 = ready2 || hit2;
-    const bool all = ready0 && ready1 && ready2;
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE2)
-    {  // when did the own group's granules / the earlier groups' accumulators become complete, and which lane was last
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime() - t_start;
-      if (!probe_done0 && __all(ready0)) { probe_done0 = true; if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = now | ((unsigned long long)polls << 32); }
-      if (!probe_done1 && __all(ready1 && ready2)) { probe_done1 = true; if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = now | ((unsigned long long)polls << 32); }
-      if (!probe_done0) probe_last0 = __ballot(!ready0);
-      if (!probe_done1) probe_last1 = __ballot(!ready1);
+    if (!ready0) {
+      const unsigned long long g = status_load(e0);
+      if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
+        ready0 = true;
+        c += (uint32_t)g & ((1u << kTileCountBits) - 1u);
+        s += (uint32_t)(g >> 32);
+      }
     }
-#endif
-#if defined(MIP_DEBUG_STAMPS) && !defined(MIP_EXP_PROBE) && !defined(MIP_EXP_PROBE2) && !defined(MIP_EXP_PROBE3)
+    if (!ready1) {
+      const unsigned long long w = status_load(e1);
+      if (((uint32_t)w >> kAccCountBits) == per_group) {  // every tile of that group has added
+        ready1 = true;
+        c += (uint32_t)w & ((1u << kAccCountBits) - 1u);
+        s += (uint32_t)(w >> 32);
+      }
+    }
+    if (!ready2) {
+      const unsigned long long pc = status_load(e2), ps = status_load(e2 + 1);
+      if ((uint32_t)(pc >> 32) == a.epoch && (uint32_t)(ps >> 32) == a.epoch) {
+        ready2 = true;
+        c += (uint32_t)pc;
+        s += (uint32_t)ps;
+      }
+    }
+    const bool all = ready0 && ready1 && ready2;
+#ifdef MIP_DEBUG_STAMPS
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
@@ -531,18 +485,8 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
       ok = false;
       break;
     }
-    #ifdef MIP_EXP_SLEEP
-    __builtin_amdgcn_s_sleep(MIP_EXP_SLEEP);
-#else
     __builtin_amdgcn_s_sleep(1);
-#endif
   }
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE2)
-  if (a.stamps && lane == 0) {  // slots 1 and 2 (computed / published stamps) are given up in this build: the last unready lanes
-    a.stamps[(size_t)blockIdx.x * 8 + 1] = probe_last0;
-    a.stamps[(size_t)blockIdx.x * 8 + 2] = probe_last1;
-  }
-#endif
   if (ok) {
     base_count = wave_sum(c);
     base_sum = wave_sum(s);
@@ -766,28 +710,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 #else
   const bool skip_publish = false;
 #endif
-#ifdef MIP_EXP_SCALAR_PUBLISH
-  if (want_cmds) {
-    unsigned long long all = 0;
-    if (lane == 63u) {
-      const uint32_t wc = (uint32_t)__popcll(keep_mask);
-      s_wave_count[wave] = wc;
-      s_wave_sum[wave] = incl_sum;
-      const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | wc;
-      all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
-    }
-    const uint32_t all_lo = __builtin_amdgcn_readlane((uint32_t)all, 63), all_hi = __builtin_amdgcn_readlane((uint32_t)(all >> 32), 63);
-    if ((all_lo >> kAggArrivalShift) == kWaves && !skip_publish) {
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE)
-      const unsigned long long q0 = __builtin_amdgcn_s_memrealtime();
-#endif
-      publish_aggregate_scalar(a, tile, all_lo & 0xffffu, all_hi);
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE)
-      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime() - q0;
-#endif
-    }
-  }
-#else
   if (want_cmds && lane == 63u) {
     const uint32_t wc = (uint32_t)__popcll(keep_mask);
     s_wave_count[wave] = wc;
@@ -796,18 +718,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     const unsigned long long all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
     // Published before any bulk store of this wave and without waiting for a barrier: the
     // successors' look-ups depend on it, nothing else does.
-    if (((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish) {
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE)
-      const unsigned long long q0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    if (((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish)
       publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // until the granule store and the accumulator add are acknowledged
-      if (a.stamps) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime() - q0;
-#endif
-    }
   }
-#endif
 
   // ---- stage the matrix rows for the transposed store (three conflict-free ds_write_b128, 48-B pitch) ----
   if (a.model || a.tlas_instances) {
@@ -910,22 +823,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     MIP_STAMP(3);
     if (wave != 0) return;
     uint32_t base_count = 0, base_sum = 0;
-#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_PROBE)
-    if (a.stamps) {  // latency of one scalar (glc) and one vector (sc1) load of an L2-resident word, behind this tile's stores
-      typedef unsigned int probe_u32x2 __attribute__((ext_vector_type(2)));
-      const unsigned long long* pp = &a.status0[tile];
-      probe_u32x2 w;
-      const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
-      asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(pp) : "memory");
-      const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long g = status_load(pp + (lane & 0u));
-      asm volatile("s_waitcnt vmcnt(0)" :: "v"(g) : "memory");
-      const unsigned long long p2 = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0) {
-        a.stamps[(size_t)blockIdx.x * 8 + 7] = (p2 - p1) + (w[0] & 0u) + ((p1 - p0) & 0u);
-      }
-    }
-#endif
     if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
     if (lane == 0 && tile == a.n_tiles - 1u) {
       *a.draw_count = base_count + tile_count;

@@ -64,39 +64,6 @@ def main():
     wait_pred = np.maximum(pred_pub - t[:, 3], 0)
     print(f"  time spent waiting for the slowest predecessor to publish: mean {wait_pred.mean():.2f} p50 {np.median(wait_pred):.2f} p90 {np.percentile(wait_pred, 90):.2f} max {wait_pred.max():.2f}")
     print(f"  poll iterations per tile: mean {st[:, 6].mean():.1f} p50 {np.median(st[:, 6]):.0f} max {st[:, 6].max()}; unready lane-polls per tile mean {st[:, 7].mean():.1f}")
-    if os.environ.get("MIP_STAMPS_PROBE"):  # build with EXTRA=-DMIP_EXP_PROBE: slots 6 / 7 = latency of one scalar / one vector load at the look-up
-        for name, sel in (("all tiles", slice(None)), ("first 2048", slice(0, 2048)), ("last 256", slice(-256, None)), ("last 64", slice(-64, None))):
-            sc, ve = t[sel, 6], t[sel, 7]
-            print(f"  probe {name:10s}: publish (store + add) acknowledged after p50 {np.median(sc):5.2f} p90 {np.percentile(sc, 90):5.2f} max {sc.max():5.2f} | vector sc1 load (issued after it) p50 {np.median(ve):5.2f} p90 {np.percentile(ve, 90):5.2f} max {ve.max():5.2f} us")
-    if os.environ.get("MIP_STAMPS_PROBE") == "2":  # EXTRA=-DMIP_EXP_PROBE2: slots 6/7 = (polls << 32 | ticks) until the own group's granules / the accumulators were complete; 1/2 = last unready lanes
-        shift = 4 if tiles <= 512 else (5 if tiles <= 2048 else 6)
-        for name, sel in (("all tiles", np.arange(tiles)), ("last 256", np.arange(tiles - 256, tiles)), ("last 64", np.arange(tiles - 64, tiles))):
-            sel = sel[sel > 0]
-            t0r, p0 = (st[sel, 6] & 0xFFFFFFFF) / 100.0, st[sel, 6] >> 32
-            t1r, p1 = (st[sel, 7] & 0xFFFFFFFF) / 100.0, st[sel, 7] >> 32
-            print(f"  probe2 {name:10s}: own group's granules complete after p50 {np.median(t0r):5.2f} p90 {np.percentile(t0r, 90):5.2f} max {t0r.max():5.2f} us (polls p50 {np.median(p0):.0f}); "
-                  f"accumulators complete after p50 {np.median(t1r):5.2f} p90 {np.percentile(t1r, 90):5.2f} max {t1r.max():5.2f} us (polls p50 {np.median(p1):.0f}); level 0 last: {np.mean(t0r >= t1r):.2f} of tiles")
-            d0, d1 = [], []
-            for q in sel:
-                r = q & ((1 << shift) - 1)
-                g = q >> shift
-                m0, m1 = int(st[q, 1]), int(st[q, 2])
-                if m0:
-                    d0.append(r - (m0.bit_length() - 1))  # distance (in tiles) of the nearest unready granule at the last incomplete poll
-                if m1:
-                    g_lo = max(0, g - 64)
-                    d1.append(g - (g_lo + m1.bit_length() - 1))
-            if d0:
-                print(f"      nearest tile still unready at the last incomplete poll: distance p50 {np.median(d0):.0f} p90 {np.percentile(d0, 90):.0f} max {max(d0)} ({len(d0)} tiles polled more than once for level 0)")
-            if d1:
-                print(f"      nearest group still incomplete at the last incomplete poll: distance p50 {np.median(d1):.0f} p90 {np.percentile(d1, 90):.0f} max {max(d1)} ({len(d1)} tiles polled more than once for level 1)")
-    if os.environ.get("MIP_STAMPS_PROBE") == "3":  # EXTRA=-DMIP_EXP_PROBE3: slot 6 / 7 = one gather of the own group's granules / of the accumulators, serialised
-        shift = 4 if tiles <= 512 else (5 if tiles <= 2048 else 6)
-        q = np.arange(tiles)
-        r, g = q & ((1 << shift) - 1), q >> shift
-        for name, sel in (("all tiles", q > 0), ("last 256", q >= tiles - 256), ("r >= 32, g >= 32", (r >= 32) & (g >= 32)), ("r < 8, g >= 32", (r < 8) & (g >= 32)), ("r >= 32, g < 8", (r >= 32) & (g < 8) & (g > 0))):
-            a0, a1 = t[sel, 6], t[sel, 7]
-            print(f"  probe3 {name:18s}: granules gather p50 {np.median(a0):5.2f} p90 {np.percentile(a0, 90):5.2f} max {a0.max():5.2f} | accumulators gather p50 {np.median(a1):5.2f} p90 {np.percentile(a1, 90):5.2f} max {a1.max():5.2f} us")
     life = t[:, 5] - t[:, 0]
     print(f"  block lifetime mean {life.mean():.2f} p50 {np.median(life):.2f} max {life.max():.2f}")
     # start time vs tile index (dispatch order)
