@@ -1441,7 +1441,10 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
   if (ctx->slots.size() != 1) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "the sharded exchange needs frames_in_flight = 1");
   if (ctx->comm) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "communicator already initialised");
   const RcclApi* r = rccl();
-  if (!r) return fail(ctx, MIP_ERR_DEVICE, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  if (!r) {
+    const char* why = dlerror();  // one call: dlerror() clears the message it returns
+    return fail(ctx, MIP_ERR_DEVICE, "the collective library (MIP_COMM_LIBRARY or librccl.so.1) could not be loaded: %s", why ? why : "symbols missing");
+  }
   if (int32_t rc = bind_device(ctx)) return rc;
   ncclUniqueId nid;
   std::memcpy(&nid, id, sizeof nid);
@@ -1454,11 +1457,15 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
   ctx->comm_world = world;
   const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
   const size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;
-  MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
-  MIP_HIP(ctx, hipMemsetAsync(ctx->d_send, 0, stride, ctx->stream));
-  MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
-  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MIP_OK;
+  const int32_t rc = [&]() -> int32_t {
+    MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
+    MIP_HIP(ctx, hipMemsetAsync(ctx->d_send, 0, stride, ctx->stream));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
+    MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MIP_OK;
+  }();
+  if (rc != MIP_OK) (void)mip_comm_destroy(ctx);  // no half-initialised communicator: the caller may retry with a smaller context
+  return rc;
 }
 
 int32_t mip_comm_destroy(MipContext* ctx) {
