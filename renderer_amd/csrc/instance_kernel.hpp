@@ -155,6 +155,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // 16-byte streaming store of an output that this launch never reads again: non-temporal
 // (global_store_dwordx4 ... nt). Measured on whole 1-KiB-per-instruction streams: the byte mover of
 // tools/micro/floor_1m.hip 17.1 -> 15.9 us at 1 M instances, this kernel 21.5 -> 20.0 us.
+// (Pointer form: the skinning palette, where the descriptor form below measured 3 % slower.)
 __device__ __forceinline__ void store_stream16(float4* p, float4 v) {
 #ifndef MIP_EXP_NO_NT
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -162,6 +163,26 @@ __device__ __forceinline__ void store_stream16(float4* p, float4 v) {
 #else
   *p = v;
 #endif
+}
+
+// The same through a buffer descriptor, with the cache-policy bits of the instruction chosen explicitly
+// (gfx940+ encoding of the builtin's last operand: 1 = sc0, 2 = nt, 16 = sc1). The descriptor's byte count
+// bounds the store: lanes past it are dropped by the hardware, so the caller needs no range test.
+// `sc1 nt` (streaming AND written through at device scope: the L2 keeps no dirty line to evict later) is the
+// fastest encoding for the matrix stream at every size — tools/micro/store_bits.hip (byte mover, 1 M instances,
+// loads + matrix stores): plain 16.1 us, nt 14.8, sc1 nt 13.9; 10 M: 175 / 167 / 164 — and in this kernel:
+// 1 M 19.6 -> 18.5-19.1 us, 10 M 182.6 -> 178.5, 200 k 7.2 -> 7.0 (profiles/r02_store_policy_ab.txt).
+// `sc1` without `nt` is as good at 1 M and collapses at 4 M (83 us against 64).
+#ifndef MIP_STORE_AUX
+#define MIP_STORE_AUX 18  // sc1 nt
+#endif
+typedef unsigned int stream_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_descriptor(void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+}
+__device__ __forceinline__ void store_stream16(__amdgpu_buffer_rsrc_t d, uint32_t byte_offset, float4 v) {
+  const stream_u32x4 w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(w, d, (int)byte_offset, 0, MIP_STORE_AUX);
 }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
@@ -734,6 +755,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   // One 1-KiB piece = 16 staged matrices -> one store instruction of a wave (64 B per matrix,
   // lane-contiguous 16-B stores). Piece p of the tile covers instances tile_first + 16 p ...
+  // descriptors of this tile's 16 KiB of matrices (and TLAS rows): bounded at the last instance
+  const uint32_t tile_bytes = (a.n - tile_first < kTile ? a.n - tile_first : kTile) * 64u;
+  const __amdgpu_buffer_rsrc_t d_model = stream_descriptor(a.model ? a.model + (size_t)tile_first * 4 : nullptr, a.model ? tile_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t d_tlas = stream_descriptor(a.tlas_instances ? a.tlas_instances + (size_t)tile_first * 4 : nullptr, a.tlas_instances ? tile_bytes : 0u);
   auto store_piece = [&](uint32_t p) {
     const uint32_t local = 16u * p + (lane >> 2);  // matrix within the tile
     const uint32_t col = lane & 3u;
@@ -745,8 +770,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
         const uint32_t bits = s_row3[local] & 15u;
         if ((bits >> col) & 1u) w = __uint_as_float(0x7fc00000u);
       }
-      if (in_range)
-        store_stream16(&a.model[(size_t)tile_first * 4 + 64u * p + lane], make_float4(src[3u * col], src[3u * col + 1u], src[3u * col + 2u], w));
+      store_stream16(d_model, (64u * p + lane) * 16u, make_float4(src[3u * col], src[3u * col + 1u], src[3u * col + 2u], w));
     }
     // optional TLAS instance rows (acceleration_strucures.rs:419-451), same transposed store:
     // VkAccelerationStructureInstanceKHR = { 3x4 row-major transform = rows 0..2 of M,
@@ -763,9 +787,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
         v = make_uint4(((first_instance_base + draw) & 0xffffffu) | 0xff000000u, 0x01000000u,
                        (uint32_t)blas, (uint32_t)(blas >> 32));
       }
-      if (in_range)
-        store_stream16(reinterpret_cast<float4*>(&a.tlas_instances[(size_t)tile_first * 4 + 64u * p + lane]),
-                       make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+      store_stream16(d_tlas, (64u * p + lane) * 16u, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
     }
   };
   // optional world AABB (mins, maxs) as the ECS component holds it: 24 B per lane

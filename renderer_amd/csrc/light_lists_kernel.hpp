@@ -72,12 +72,17 @@ __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const Light
     uint32_t* dst = a.out + ((size_t)l * a.n + first) * kCmdWords;
     if constexpr (kAligned16) {
       // n % 4 == 0: every tile row starts on a 16-B boundary and in_tile % 4 == 0
+#if !defined(MIP_EXP_LIGHT_NO_NT) && !defined(MIP_EXP_LIGHT_PTR_NT)  // sc1 nt: 1 M x 16 lights 61.4 -> 56.7 us against the pointer form's nt
+      const __amdgpu_buffer_rsrc_t d_dst = stream_descriptor(dst, words * 4u);
+#endif
       for (uint32_t q = tid; q * 4u < words; q += kTile) {
         const uint4 v = reinterpret_cast<const uint4*>(row)[q];
-#ifdef MIP_EXP_LIGHT_NO_NT
+#if defined(MIP_EXP_LIGHT_NO_NT)
         reinterpret_cast<uint4*>(dst)[q] = v;
-#else  // written once, lane-contiguous 16-B stores: non-temporal, as the matrices of the instance kernel
+#elif defined(MIP_EXP_LIGHT_PTR_NT)
         store_stream16(reinterpret_cast<float4*>(dst) + q, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+#else  // written once, lane-contiguous 16-B stores: streamed like the matrices of the instance kernel
+        store_stream16(d_dst, q * 16u, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
 #endif
       }
     } else {
