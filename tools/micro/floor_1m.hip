@@ -20,14 +20,17 @@ struct Args {
   float4* model; uint32_t* bitmap; uint32_t* cmds; uint32_t n;
 };
 
-template <bool kNT>
+// kNT: 0 = plain, 1 = non-temporal, 2 = 'sc1 nt' (streamed and written through at device scope; what the pipeline uses)
+template <int kNT>
 __device__ __forceinline__ void store16(float4* p, float4 v) {
   typedef float v4f __attribute__((ext_vector_type(4)));
-  if constexpr (kNT) __builtin_nontemporal_store((v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p)); else *p = v;
+  if constexpr (kNT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n s_nop 1" :: "v"(p), "v"((v4f){v.x, v.y, v.z, v.w}) : "memory");
+  else if constexpr (kNT == 1) __builtin_nontemporal_store((v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+  else *p = v;
 }
 
 // one tile of 256 instances handled by the 256 threads of a workgroup
-template <bool kLoads, bool kStores, bool kNT>
+template <bool kLoads, bool kStores, int kNT>
 __device__ __forceinline__ void move_tile(const Args& a, uint32_t tile) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t i = tile * 256u + tid;
@@ -63,13 +66,13 @@ __device__ __forceinline__ void move_tile(const Args& a, uint32_t tile) {
   }
 }
 
-template <bool kLoads, bool kStores, bool kNT, int kPerWg>
+template <bool kLoads, bool kStores, int kNT, int kPerWg>
 __global__ __launch_bounds__(256) void mover(const Args a) {
 #pragma unroll
   for (int k = 0; k < kPerWg; ++k) move_tile<kLoads, kStores, kNT>(a, blockIdx.x * kPerWg + k);
 }
 
-template <bool kNT>
+template <int kNT>
 __global__ __launch_bounds__(256) void mover_persistent(const Args a, uint32_t n_tiles) {
   for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) move_tile<true, true, kNT>(a, t);
 }
@@ -105,19 +108,23 @@ int main(int argc, char** argv) {
         {"persistent 256 x 8, non-temporal", bytes_full, 6},
         {"loads only (36 B)", n * 36.0, 7},
         {"stores only (64 B + bitmap + commands)", bytes_full - n * 36.0, 8},
+        {"1 tile / WG, 'sc1 nt' matrix stores", bytes_full, 9},
+        {"stores only, 'sc1 nt' matrix stores", bytes_full - n * 36.0, 10},
     };
     for (const V& v : variants) {
       auto launch = [&]() {
         switch (v.id) {
-          case 0: hipLaunchKernelGGL((mover<true, true, false, 1>), dim3(tiles), dim3(256), 0, st, a); break;
-          case 1: hipLaunchKernelGGL((mover<true, true, false, 2>), dim3((tiles + 1) / 2), dim3(256), 0, st, a); break;
-          case 2: hipLaunchKernelGGL((mover<true, true, false, 4>), dim3((tiles + 3) / 4), dim3(256), 0, st, a); break;
-          case 3: hipLaunchKernelGGL((mover_persistent<false>), dim3(std::min(tiles, 2048u)), dim3(256), 0, st, a, tiles); break;
-          case 4: hipLaunchKernelGGL((mover_persistent<false>), dim3(std::min(tiles, 1024u)), dim3(256), 0, st, a, tiles); break;
-          case 5: hipLaunchKernelGGL((mover<true, true, true, 1>), dim3(tiles), dim3(256), 0, st, a); break;
-          case 6: hipLaunchKernelGGL((mover_persistent<true>), dim3(std::min(tiles, 2048u)), dim3(256), 0, st, a, tiles); break;
-          case 7: hipLaunchKernelGGL((mover<true, false, false, 1>), dim3(tiles), dim3(256), 0, st, a); break;
-          case 8: hipLaunchKernelGGL((mover<false, true, false, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 0: hipLaunchKernelGGL((mover<true, true, 0, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 1: hipLaunchKernelGGL((mover<true, true, 0, 2>), dim3((tiles + 1) / 2), dim3(256), 0, st, a); break;
+          case 2: hipLaunchKernelGGL((mover<true, true, 0, 4>), dim3((tiles + 3) / 4), dim3(256), 0, st, a); break;
+          case 3: hipLaunchKernelGGL((mover_persistent<0>), dim3(std::min(tiles, 2048u)), dim3(256), 0, st, a, tiles); break;
+          case 4: hipLaunchKernelGGL((mover_persistent<0>), dim3(std::min(tiles, 1024u)), dim3(256), 0, st, a, tiles); break;
+          case 5: hipLaunchKernelGGL((mover<true, true, 1, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 6: hipLaunchKernelGGL((mover_persistent<1>), dim3(std::min(tiles, 2048u)), dim3(256), 0, st, a, tiles); break;
+          case 7: hipLaunchKernelGGL((mover<true, false, 0, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 8: hipLaunchKernelGGL((mover<false, true, 0, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 9: hipLaunchKernelGGL((mover<true, true, 2, 1>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 10: hipLaunchKernelGGL((mover<false, true, 2, 1>), dim3(tiles), dim3(256), 0, st, a); break;
         }
       };
       const int K = n >= 10000000u ? 40 : 200;
