@@ -448,3 +448,37 @@ def test_recorded_graphs_follow_the_census(ra, oracle_mod):
         p.run_many(frame, outs, 128); p.wait()
         check("finite again")
         assert p.timings()["graph_records"] == 3
+
+
+@pytest.mark.parametrize("order", [1, 3])
+def test_streamed_outputs_stop_at_the_last_instance(ra, oracle_mod, order, monkeypatch):
+    """The matrix and TLAS streams go out through buffer descriptors bounded at the tile's last instance
+    (the hardware drops lanes past it, there is no range test in the kernel): ragged sizes must fill exactly
+    n x 64 bytes — the words before and after stay untouched — with the oracle's values."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    monkeypatch.setenv("MIP_TUNE_ORDER", str(order))
+    dev = torch.device("cuda", 0)
+    guard = 1024  # floats either side
+    for n in (1, 3, 255, 256, 257, 1000, 65_537):
+        s = ra.scene.make_scene(3, n=n)
+        want = run_oracle(oracle_mod, s)
+        with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            model = torch.full((guard + n * 16 + guard,), -7.25, dtype=torch.float32, device=dev)
+            tlas = torch.full((guard + n * 16 + guard,), -7.25, dtype=torch.float32, device=dev)
+            cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            p.run_device(make_frame(s["planes"], s["cam_pos"]), model=model.data_ptr() + guard * 4,
+                         tlas_instances=tlas.data_ptr() + guard * 4, draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
+                         draw_index_total=scal.data_ptr() + 4)
+            torch.cuda.synchronize()
+            m, t = model.cpu().numpy(), tlas.cpu().numpy()
+        for name, arr in (("model", m), ("tlas", t)):
+            assert (arr[:guard] == -7.25).all() and (arr[guard + n * 16:] == -7.25).all(), (name, order, n)
+            assert not (arr[guard:guard + n * 16].view(np.uint32) == np.float32(-7.25).view(np.uint32)).all(), (name, order, n)
+        got = m[guard:guard + n * 16].reshape(n, 16)
+        np.testing.assert_array_equal(got.view(np.uint32), np.asarray(want["model"], np.float32).reshape(n, 16).view(np.uint32), err_msg=str((order, n)))
