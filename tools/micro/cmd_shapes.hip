@@ -17,7 +17,7 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 struct Args { const float* pos; const float4* rot; const float* scale; const uint32_t* mesh; float4* model; uint32_t* bitmap; uint32_t* cmds; uint32_t n; };
 
-template <int kCmd, bool kBitmap, bool kSmallFirst = false>
+template <int kCmd, bool kBitmap, bool kSmallFirst = false, bool kBitmapThrough = false>
 __global__ __launch_bounds__(256) void mover(const Args a) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
   const uint32_t i = tile * 256u + tid;
@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256) void mover(const Args a) {
   if constexpr (kSmallFirst) return;
   if constexpr (kBitmap) {
     const unsigned long long vis = __ballot(px > 0.f);
-    if (lane < 2u && i < a.n) a.bitmap[(tile * 256u >> 5) + wave * 2u + lane] = (uint32_t)(vis >> (32u * lane));
+    if (lane < 2u && i < a.n) {
+      uint32_t* b = &a.bitmap[(tile * 256u >> 5) + wave * 2u + lane];
+      const uint32_t w = (uint32_t)(vis >> (32u * lane));
+      if constexpr (kBitmapThrough) asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(b), "v"(w) : "memory");
+      else *b = w;
+    }
   }
   if (!full) return;
   const uint32_t w0 = __float_as_uint(px) + mesh, w1 = __float_as_uint(sc);
@@ -90,7 +95,9 @@ int main() {
     const V vs[] = {{"no commands, no bitmap", 0}, {"bitmap only", 1}, {"commands as dword stores (the pipeline's shape) + bitmap", 2},
                     {"commands as aligned 16-byte stores (padded) + bitmap", 3}, {"commands as aligned 16-byte 'sc1 nt' stores + bitmap", 4},
                     {"commands as 'nt' dword stores + bitmap", 5}, {"commands as dword stores, no bitmap", 6},
-                    {"bitmap + commands (dword) issued BEFORE the matrix stores", 7}};
+                    {"bitmap + commands (dword) issued BEFORE the matrix stores", 7},
+                    {"bitmap only, written through (sc1): nothing left dirty in the L2", 8},
+                    {"bitmap sc1 + commands aligned 16-byte 'sc1 nt': nothing left dirty", 9}};
     for (const V& v : vs) {
       auto launch = [&]() {
         switch (v.id) {
@@ -102,6 +109,8 @@ int main() {
           case 5: hipLaunchKernelGGL((mover<4, true>), dim3(tiles), dim3(256), 0, st, a); break;
           case 6: hipLaunchKernelGGL((mover<1, false>), dim3(tiles), dim3(256), 0, st, a); break;
           case 7: hipLaunchKernelGGL((mover<1, true, true>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 8: hipLaunchKernelGGL((mover<0, true, false, true>), dim3(tiles), dim3(256), 0, st, a); break;
+          case 9: hipLaunchKernelGGL((mover<3, true, false, true>), dim3(tiles), dim3(256), 0, st, a); break;
         }
       };
       const int K = n >= 10000000u ? 40 : 200;
