@@ -39,6 +39,7 @@ def main():
             "no_cmds": dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr()),
             "bitmap_only": dict(visible_bitmap=bitmap.data_ptr()),
             "model_only": dict(model=model.data_ptr()),
+            "model+cmds (no bitmap)": dict(model=model.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4),
             "full+aabb": dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
                               draw_count=scal.data_ptr(), world_aabb=aabb.data_ptr()),
         }

@@ -86,7 +86,9 @@ int main() {
     CHECK(hipMalloc(&scale, (size_t)n * 4)); CHECK(hipMalloc(&mesh, (size_t)n * 4));
     CHECK(hipMemset(pos, 0x3f, (size_t)n * 12)); CHECK(hipMemset(rot, 0x3f, (size_t)n * 16));
     CHECK(hipMemset(scale, 0x3f, (size_t)n * 4)); CHECK(hipMemset(mesh, 0, (size_t)n * 4));
-    CHECK(hipMalloc(&a.model, (size_t)(tiles + 4) * 256 * 64));
+    float4* model_all;
+    CHECK(hipMalloc(&model_all, (size_t)(tiles + 4) * 256 * 64 + (size_t)(tiles + 4) * 32 + 256 + (size_t)(tiles + 4) * 4 * 96 * 4));
+    a.model = model_all;
     CHECK(hipMalloc(&a.bitmap, (size_t)(tiles + 4) * 32));
     CHECK(hipMalloc(&a.cmds, (size_t)(tiles + 4) * 4 * 96 * 4));
     a.pos = pos; a.rot = rot; a.scale = scale; a.mesh = mesh; a.n = n;
@@ -98,7 +100,13 @@ int main() {
                     {"bitmap + commands (dword) issued BEFORE the matrix stores", 7},
                     {"bitmap only, written through (sc1): nothing left dirty in the L2", 8},
                     {"bitmap sc1 + commands aligned 16-byte 'sc1 nt': nothing left dirty", 9}};
+    for (int alias = 0; alias < 2; ++alias) {
+    // alias = 1: the visibility words and commands live at the end of the matrix allocation (same pages, same region)
+    Args b = a;
+    if (alias) { b.bitmap = reinterpret_cast<uint32_t*>(model_all + (size_t)(tiles + 4) * 256 * 4); b.cmds = b.bitmap + (size_t)(tiles + 4) * 8 + 64; }
+    printf("--- %s\n", alias ? "visibility words and commands inside the matrix allocation" : "separate allocations");
     for (const V& v : vs) {
+      const Args& a = b;
       auto launch = [&]() {
         switch (v.id) {
           case 0: hipLaunchKernelGGL((mover<0, false>), dim3(tiles), dim3(256), 0, st, a); break;
@@ -128,6 +136,7 @@ int main() {
       }
       std::sort(samples.begin(), samples.end());
       printf("n=%-9u %-60s median %7.2f us  min %7.2f us\n", n, v.name, samples[3], samples[0]);
+    }
     }
     CHECK(hipFree(pos)); CHECK(hipFree(rot)); CHECK(hipFree(scale)); CHECK(hipFree(mesh));
     CHECK(hipFree(a.model)); CHECK(hipFree(a.bitmap)); CHECK(hipFree(a.cmds));
