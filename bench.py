@@ -766,8 +766,10 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
             except Exception as e:  # noqa: BLE001
                 extra["single_gpu_same_workload"] = {"error": f"{type(e).__name__}: {e}"}
         dist.barrier()
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(s, args.cpu_seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None  # timed on rank 0 at N = 1 only (the N = 1 line carries it)
     pipe.close()
 
 
