@@ -6,7 +6,7 @@
 //   loads   : pos (12 B) + quat (16 B) + scale (4 B) + mesh id (4 B)            = 36 B
 //   compute : M = T·R·S, 8-corner world AABB, 6-plane test, LOD pick             (VALU, no FMA)
 //   stores  : mat4 through an LDS transpose so every store instruction writes
-//             1 KiB contiguous (64 B), 1 visibility bit, and — after a one-hop look-up of
+//             1 KiB contiguous (64 B per instance; buffer_store_dwordx4 ... sc1 nt), 1 visibility bit, and — after a one-hop look-up of
 //             the tile's exclusive prefix over per-tile granules and per-group atomic
 //             accumulators of {count, Σ index_len} — the tile's surviving
 //             VkDrawIndexedIndirectCommands, coalesced, in draw_index order.
@@ -594,10 +594,12 @@ constexpr uint32_t kAggArrivalShift = 24;
 // the host launches <.., .., false> whenever its upload-time census found every instance finite
 // (mesh-table boxes always are); a per-instance box override may be non-finite, so it implies kGeneral.
 // kOrder: what a workgroup does between its arithmetic and its exit (both orders produce identical bytes).
-//   1  stores first: waves 1-3 store their matrices, THEN the commands are assembled (in the staging
-//      area those waves have just freed: 13.4 KB of LDS per workgroup) and wave 0 resolves the prefix,
-//      copies the commands out and stores its own matrices last. The store issue of waves 1-3 paces
-//      the polls; best once the launch has a steady state (>= 1 M instances: 191 vs 240 us at 10 M).
+//   1  stores first: waves 1-3 store all sixteen matrix pieces, THEN the commands are assembled (in the
+//      staging area those waves have just freed: 13.4 KB of LDS per workgroup) and wave 0 resolves the
+//      prefix and copies the commands out (it has no bulk store of its own). The store issue of waves
+//      1-3 paces the look-up: a tile that looks at its predecessors' words early, while they are still
+//      being written, slows the whole launch (profiles/r02_lookup_probes.txt); best once the launch has
+//      a steady state (>= 1 M instances: 181 vs 232 us at 10 M).
 //   3  commands first: assembly in an area of its own (19.5 KB), then waves 1-3 store all sixteen
 //      matrix pieces while wave 0 spends that time on the prefix round trip and the copy-out.
 //      Shortest dependency chain per tile; best while every tile is in the launch's first and last

@@ -271,9 +271,9 @@ FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool t
   *grid = n_tiles;
   // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of
   // workgroups (8 per CU: every tile is ramp or tail), stores-first once there is a steady state.
-  // Measured on MI355X (profiles/r02_order*.txt, r02_next_generation_prefetch_ab.txt): order 3 ahead below
-  // ~0.8 M instances (200 k: 7.7 vs 8.4 us; 700 k: 14.1 vs 14.3), order 1 ahead from ~1 M (1 M: 19.7 vs 20.2;
-  // 1.25 M: 24.0 vs 24.9; 10 M: 191 vs 240 us).
+  // Measured on MI355X (profiles/r02_order*.txt, r02_next_generation_prefetch_ab.txt, r02_lookup_probes.txt):
+  // order 3 ahead below ~0.8 M instances (200 k: 7.0 vs 7.9 us; 700 k: 13.6 vs 14.3), order 1 ahead from ~1 M
+  // (2 M: 34.1 vs 35.7; 4 M: 64.4 vs 68; 10 M: 181 vs 232 us; 1 M: equal within the run-to-run spread).
   int order = n_tiles <= (uint32_t)ctx->cu_count * 14u ? 3 : 1;
   if (ctx->force_order) order = ctx->force_order;
   (void)tlas;
