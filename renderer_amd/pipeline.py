@@ -64,6 +64,7 @@ class InstancePipeline:
             raise MipError(rc, "mip_create failed (is there a gfx950 GPU?)")
         self.max_instances = int(max_instances)
         self.n = 0
+        self.stream = stream  # the caller's HIP stream handle, or None when the context created its own
 
     # -- lifetime --
     def close(self):

@@ -53,6 +53,7 @@ class DrawListExchange:
             import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.pipe, self.n_local, self.world, self.rank, self.device = pipe, int(n_local), int(world), int(rank), device
+        self._on_gpu = getattr(torch.device(device), "type", "cpu") == "cuda"
         # the kernel may emit up to n_local commands, so the send buffer always has room for all of them
         self._send_full = torch.zeros(chunk_stride_bytes(self.n_local) // 4, dtype=torch.int32, device=device)
         self.merged_count = torch.zeros(2, dtype=torch.int32, device=device)
@@ -74,6 +75,14 @@ class DrawListExchange:
         if outs is not None:
             model = outs.model.data_ptr()
             visible_bitmap = outs.bitmap.data_ptr()
+        # kernel -> all-gather -> merge are ordered by ONE stream: the collective goes to torch's current stream, so a
+        # HIP context must have been created on that very stream (the CPU stand-ins of the tests have no `stream`)
+        if self._on_gpu and hasattr(self.pipe, "stream"):
+            current = self.torch.cuda.current_stream(self.device).cuda_stream
+            if self.pipe.stream is None or int(self.pipe.stream) != int(current):
+                raise ValueError("DrawListExchange.step: the pipeline's stream is not torch's current stream — create it with "
+                                 "InstancePipeline(..., stream=torch.cuda.current_stream(device).cuda_stream) and call step() "
+                                 "under that stream; the all-gather would otherwise race with the kernels")
         base = self._send_full.data_ptr()
         self.pipe.run_device(frame, model=model, visible_bitmap=visible_bitmap, world_aabb=world_aabb,
                              draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4,

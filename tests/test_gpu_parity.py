@@ -981,3 +981,20 @@ def test_native_rccl_exchange_world_size_one(ra, oracle_mod):
     with ra.InstancePipeline(max_instances=16, max_meshes=1, frames_in_flight=2) as p2:
         with pytest.raises(ra.MipError):
             p2.comm_init(uid, 0, 1)
+
+
+def test_exchange_refuses_a_pipeline_on_another_stream(ra):
+    """kernel -> all-gather -> merge are ordered by ONE stream; a context created on its own stream would race with
+    the collective that torch issues on the current stream, so DrawListExchange.step says so instead of racing."""
+    import torch
+
+    from renderer_amd.sharded import DrawListExchange, make_shard_frame
+
+    dev = torch.device("cuda", 0)
+    s = ra.scene.make_scene(3, n=4096)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:  # its own stream
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        ex = DrawListExchange(p, s["n"], 1, 0, dev)
+        with pytest.raises(ValueError, match="current stream"):
+            ex.step(make_shard_frame(s["planes"], s["cam_pos"], s["n"], 1, 0))
