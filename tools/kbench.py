@@ -44,6 +44,12 @@ def child(configs, subset, ns):
                 kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr())
             elif subset == "no_model":
                 kw = dict(visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr())
+            elif subset == "model_only":
+                kw = dict(model=model.data_ptr())
+            elif subset == "bitmap_only":
+                kw = dict(visible_bitmap=bitmap.data_ptr())
+            elif subset != "full":
+                raise SystemExit(f"unknown --subset {subset!r}: full, no_cmds, no_model, model_only, bitmap_only")
             out = pipe.prepare_outputs(**kw)
             fref = pipe.frame_ref(make_frame(s["planes"], s["cam_pos"]))
             batch = 20 if n <= 2_000_000 else 5
