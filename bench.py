@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 MIN_SAMPLES = 50
+MIN_WARMUP_SECONDS = 0.05  # untimed launches before the timed samples of an event-timed leg, in batches of 200
 PARITY = "oracle (unpinned: the reference holds no tests, fixtures or golden vectors; SURVEY.md §8c)"
 
 
@@ -80,9 +81,15 @@ def event_samples(torch, step, steps, warmup, samples):
     """`samples` samples of `steps` back-to-back steps between two HIP events recorded on torch's current stream
     — the stream the context launches on. Returns the per-step times in ms (one per sample) and the wall-clock
     per-step times of the same samples (host launch + synchronize included)."""
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
+    # untimed warm-up: the W steps the caller asked for, and in any case about 50 ms of launches for the
+    # GPU's clocks to settle — the first hundred samples after an idle period carry a slow tail otherwise
+    # (p90 19.1 us against 18.6 once warm, same median: profiles/r02_sizes_final.txt)
+    done, t_warm = 0, time.perf_counter()
+    while done < warmup or time.perf_counter() - t_warm < MIN_WARMUP_SECONDS:
+        for _ in range(200):
+            step()
+        done += 200
+        torch.cuda.synchronize()
     ev_ms, wall_ms = [], []
     for _ in range(samples):
         e0 = torch.cuda.Event(enable_timing=True)
