@@ -467,10 +467,39 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
     return row
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: become the launcher. Runs
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD process — this
+    process has made no GPU call yet and never replaces itself (no exec) — lets rank 0's JSON line through on
+    stdout and returns the launcher's exit code, so one failed rank fails the whole run."""
+    import socket
+    import subprocess
+
+    import torch  # device_count() does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); no line printed\n")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no WORLD_SIZE in the environment, launching the ranks: " + " ".join(cmd) + "\n")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     args.steps = max(1, args.steps)
     args.warmup = max(0, args.warmup)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("MIP_BENCH_FORCE_DIST") != "1":
+        sys.exit(spawn_ranks(args))
     # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
     # JSON line on stdout. Everything else this process (and the libraries it loads) prints goes
     # to stderr; the JSON line is written to the saved stdout at the end.
@@ -496,8 +525,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE {world}")
+    if args.gpus != world and os.environ.get("MIP_BENCH_FORCE_DIST") != "1":
+        # n_gpus in the line is the world size: a line whose n_gpus is not what was asked for is never printed
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}; no line printed")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the instance pipeline has no CPU path")
     torch.cuda.set_device(local_rank)
