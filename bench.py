@@ -705,7 +705,7 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
     outs = DeviceOutputs(torch, n_local, device)
     frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=lo)
     torch.cuda.synchronize()
-    ex = DrawListExchange(pipe, n_local, world, rank, device)
+    ex = DrawListExchange(pipe, n_local, world, rank, device, wire=os.environ.get("MIP_BENCH_WIRE", "1") != "0")  # 0: A/B against 20-byte commands
     timeouts = [0]
 
     def settle():
@@ -724,25 +724,34 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
         settle()
         return out
 
+    def timeouts_anywhere():
+        """The largest timeout count over the ranks. Every decision that changes what is issued next (repeat a frame,
+        measure again) is taken on THIS number, never on the local one: a rank that repeated a frame on its own would
+        issue one all-gather more than its peers."""
+        t = torch.tensor([timeouts[0]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
     ex.step(frame, outs)
     settle()
     capacity_full = ex.capacity
     ex.tighten()   # the exchanged chunk = the largest shard list of the first frame + 6 %; an overflow is repaired, not lost
     ex.step(frame, outs)
     settle()
-    if timeouts[0]:  # the frames above are invalid: repeat them in the mode the context has fallen back to
-        ex.set_capacity(n_local)
+    if timeouts_anywhere():  # the frames above are invalid somewhere: repeat them (that rank's context has fallen back to ordered tiles)
+        ex.set_capacity(ex.n_max)
         ex.step(frame, outs)
         settle()
         ex.tighten()
     counts, _ = ex.counts()
     samples = max(10, min(args.samples, 30))
-    before = timeouts[0]
+    before = timeouts_anywhere()
     ms = timed()
-    if timeouts[0] != before:  # a frame of the timed loop expired (0.5 s stall inside the samples): measure again
+    after = timeouts_anywhere()
+    if after != before:  # a frame of the timed loop expired (0.5 s stall inside the samples): measure again
         ms = timed()
-    t = torch.tensor([timeouts[0]], dtype=torch.int64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        after = timeouts_anywhere()
+    any_timeouts = after
     med = float(np.median(ms))
     result.update({
         "value": n_total / (med * 1e-3),
@@ -758,10 +767,12 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
             "emitted_fraction": float(counts.sum()) / max(n_total, 1),
             "draw_list_exchange": "rccl all-gather (torch.distributed nccl backend) + merge kernel, inside the timed region",
             "chunk_bytes_per_rank": int(ex.stride),
+            "chunk_format": "wire: 8-byte records {firstInstance, mesh | lod} in blocks of 256 (MIP_OUT_WIRE), expanded by the merge" if ex.wire else "20-byte commands",
+            "chunk_bytes_per_rank_as_20_byte_commands": int((32 + ex.capacity * 20 + 255) // 256 * 256),
             "chunk_capacity_commands": int(ex.capacity),
             "chunk_capacity_untightened": int(capacity_full),
             "n_ranks_seen": int(dist.get_world_size()),
-            "ordered_tiles_fallback": bool(int(t.item())),
+            "ordered_tiles_fallback": bool(any_timeouts),
             "frames_in_flight": 1,
             "host_loop": "python: kernel -> all_gather_into_tensor -> merge per step on one stream",
             "outputs": "per rank: its shard's model[] + bitmap; every rank: the merged global draw list",
@@ -775,8 +786,9 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
         k_ms = barrier_samples(torch, dist, lambda: pipe.run_device(frame, async_=True, **kw), args.steps, args.warmup, 10, True)
         pipe.wait()
         g_ms = barrier_samples(torch, dist, lambda: dist.all_gather_into_tensor(ex.recv, ex.send), args.steps, 3, 10, True)
-        m_ms = barrier_samples(torch, dist, lambda: pipe.merge_draw_lists(ex.recv.data_ptr(), world, ex.stride, ex.merged.data_ptr(),
-                                                                          ex.merged_count.data_ptr(), async_=True, chunk_capacity=ex.capacity),
+        merge_fn = pipe.merge_wire_lists if ex.wire else pipe.merge_draw_lists
+        m_ms = barrier_samples(torch, dist, lambda: merge_fn(ex.recv.data_ptr(), world, ex.stride, ex.merged.data_ptr(),
+                                                             ex.merged_count.data_ptr(), async_=True, chunk_capacity=ex.capacity),
                                args.steps, 3, 10, True)
         pipe.wait()
         result["breakdown_ms_per_step"] = {

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIP_ABI_VERSION 2u
+#define MIP_ABI_VERSION 3u
 
 /* ---- status codes (0 = success, negative = error; like VkResult in vma) ---- */
 #define MIP_OK 0
@@ -67,6 +67,10 @@ extern "C" {
                               * OTHER streams for those buffers (a clear, a previous reader) is not waited for —
                               * order it with an event / synchronize, or hand the library that stream */
 #define MIP_OUT_ASYNC 0x2u  /* with MIP_OUT_DEVICE: return after enqueue; pair with mip_wait */
+#define MIP_OUT_WIRE 0x4u   /* with MIP_OUT_DEVICE: draw_cmds receives the list in the WIRE form below (8.06 B per
+                              * command instead of 20) — what a rank sends through the all-gather; draw_count and
+                              * draw_index_total as usual. Not with culled_index_buffer (the wire form carries no
+                              * indexCount: it is the mesh table's). mip_merge_wire_lists expands it again. */
 
 /* Largest LOD chain the scene loader can produce: LOD0 + 5 simplified levels
  * (src/renderer/systems/scene_loader.rs:740-753). */
@@ -143,7 +147,10 @@ typedef struct MipOutputs {
    * of one scene are merged (mip_merge_draw_lists). May be NULL. */
   uint32_t* draw_index_total;
   /* Optional: N x {mins[3], maxs[3]} world AABB as the ECS `AABB` component holds it
-   * (src/ecs/components.rs:18-20). May be NULL. */
+   * (src/ecs/components.rs:18-20). May be NULL. Identical to the reference's values AS NUMBERS; the sign
+   * of a coordinate that is exactly zero is not specified (the kernel folds the box without enumerating
+   * the corners where that is exact — a zero may come out as +0 where the corner loop gives -0 — and which
+   * arithmetic tier runs depends on the other instances of the scene). Visibility does not depend on it. */
   void* world_aabb;
   uint32_t flags; /* MIP_OUT_* */
   uint32_t reserved;
@@ -176,6 +183,7 @@ typedef struct MipTimings {
   uint64_t graph_frames;      /* frames mip_run_many replayed from recorded launch graphs (counted even without MIP_CFG_TIMING) */
   uint64_t graph_records;     /* times it had to record a new set of graphs */
   uint64_t sharded_retries;   /* sharded frames whose tightened chunk overflowed and were re-gathered at full capacity */
+  uint64_t sharded_bytes_sent; /* bytes this rank contributed to the last sharded frame's all-gather */
   uint64_t general_launches;  /* frames launched with the kernel that carries the literal path for non-finite
                                  inputs (some resident instance failed the upload-time finite test, or a skinned frame) */
 } MipTimings;
@@ -188,6 +196,26 @@ typedef struct MipShardHeader {
   uint32_t reserved[6];
 } MipShardHeader;
 
+/* ---- wire form of a shard's draw list (MIP_OUT_WIRE, mip_merge_wire_lists) ---------------------
+ * An emitted command of cull_pass (cull_pipeline.rs:534-577) is determined by its draw_index, its
+ * mesh, the LOD picked and its position in the running index sum: indexCount = index_len[lod] and
+ * vertexOffset come from the mesh table every rank holds, instanceCount is 1 (generate_work.comp:63).
+ * The wire form therefore carries per command the 8-byte record
+ *     { firstInstance, mesh_id | lod << 31 }            lod = 0 or 1 (pick_lod, helpers.rs:3-11)
+ * in blocks of MIP_WIRE_BLOCK_COMMANDS records, each block behind a 16-byte block header whose
+ * first word is the firstIndex of the block's first command (relative to the shard, plus the
+ * frame's first_index_base, as the 20-byte form has it); the firstIndex of the others is that plus
+ * the index_len of the records in front of them within the block. Block b of a list lives at byte
+ * b * MIP_WIRE_BLOCK_BYTES of the body; a list cut after any whole number of blocks is a valid
+ * shorter list, which is what lets a rank send a tightened slice of it. */
+#define MIP_WIRE_BLOCK_COMMANDS 256u
+#define MIP_WIRE_BLOCK_HEADER_BYTES 16u
+#define MIP_WIRE_RECORD_BYTES 8u
+#define MIP_WIRE_BLOCK_BYTES (MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_RECORD_BYTES) /* 2064 */
+/* bytes of the body of a wire list with room for `capacity` commands (whole blocks) */
+#define MIP_WIRE_BODY_BYTES(capacity) \
+  ((((uint64_t)(capacity) + MIP_WIRE_BLOCK_COMMANDS - 1u) / MIP_WIRE_BLOCK_COMMANDS) * MIP_WIRE_BLOCK_BYTES)
+
 uint32_t mip_abi_version(void);
 
 /* Create a context on cfg->device_ordinal. Allocates device storage for
@@ -199,7 +227,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out);
 void mip_destroy(MipContext* ctx);
 
 /* Copy the mesh table to the device (caller keeps its memory). m <= max_meshes.
- * Bounds must be finite and n_lods in 1..MIP_MAX_LODS. */
+ * Bounds must be finite and n_lods in 1..MIP_MAX_LODS. A table smaller than the one it replaces is refused
+ * (MIP_ERR_INVALID_ARGUMENT, nothing changes) while a resident instance names a mesh outside it. */
 int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m);
 
 /* Upload the instance columns: SoA, tightly packed, draw_index = array index
@@ -219,8 +248,9 @@ int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* ro
 int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, const float* pos_xyz,
                              const float* rot_ijkw, const float* scale, const uint32_t* mesh_id);
 
-/* Same, from DEVICE pointers of the context's GPU (device-to-device copies; mesh ids are
- * not validated — the caller guarantees id < m). */
+/* Same, from DEVICE pointers of the context's GPU (device-to-device copies). Mesh ids are checked on the
+ * device after the copy (the upload-time census reads every instance anyway): an id >= m fails the call with
+ * MIP_ERR_INVALID_ARGUMENT and leaves NO instances resident. */
 int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const void* rot_ijkw,
                                  const void* scale, const void* mesh_id, uint32_t n);
 
@@ -337,11 +367,22 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
                              uint64_t chunk_stride_bytes, uint32_t chunk_capacity, void* out_cmds,
                              uint32_t* out_count, int32_t async);
 
+/* The same merge for chunks in the WIRE form (each: MipShardHeader followed by a wire body, see
+ * MIP_OUT_WIRE): every record is expanded against THIS context's mesh table — which must be the table
+ * the emitting ranks ran with; it is replicated by construction — into the 20-byte
+ * command, and the result is byte-identical to mip_merge_draw_lists over the 20-byte chunks of the
+ * same frames. chunk_stride_bytes >= sizeof(MipShardHeader) + MIP_WIRE_BODY_BYTES(chunk_capacity);
+ * chunk_capacity = 0 means what the stride holds in whole blocks. A record whose mesh id is outside the table (a corrupt chunk)
+ * is expanded as mesh 0 and reported as MIP_ERR_DEVICE. */
+int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks,
+                             uint64_t chunk_stride_bytes, uint32_t chunk_capacity, void* out_cmds,
+                             uint32_t* out_count, int32_t async);
+
 /* ---- sharded scenes without a Python host: RCCL straight from the library ------------------
  * librccl.so.1 is opened with dlopen on first use, so single-GPU hosts do not need it. The
  * exchange is the one of SURVEY.md §8e: every rank runs its shard, ONE ncclAllGather moves the
- * fixed-size chunks [MipShardHeader | chunk_capacity x 20 B], mip_merge_draw_lists' kernel
- * concatenates them. Needs a context with one frame in flight. */
+ * fixed-size chunks [MipShardHeader | wire body for chunk_capacity commands: 8.06 B each instead of
+ * 20, see MIP_OUT_WIRE], mip_merge_wire_lists' kernel expands and concatenates them. Needs a context with one frame in flight. */
 #define MIP_COMM_ID_BYTES 128u
 
 /* ncclGetUniqueId: call on one rank, hand the 128 bytes to the others by any means. */
@@ -356,12 +397,14 @@ typedef struct MipShardedOutputs {
   void* world_aabb;         /* this rank's shard, or NULL */
   void* draw_cmds;          /* the MERGED global list; room for world x chunk_capacity commands */
   uint32_t* draw_count;     /* [0] merged command count, [1] merged index total */
-  uint32_t chunk_capacity;  /* commands each rank contributes at most; 0 = the context's max_instances.
+  uint32_t chunk_capacity;  /* commands each rank contributes at most; 0 = the largest max_instances over the ranks
+                               (mip_comm_init settles on it with a 4-byte all-gather, so ranks created for
+                               shards of different sizes still exchange chunks of one size).
                                If ANY rank emits more, every rank sees it in the gathered headers and the
                                library repeats the all-gather + merge of that frame once at full capacity
                                (at once for a synchronous call, inside mip_wait for an asynchronous one;
                                MipTimings.sharded_retries counts them): draw_cmds therefore needs room for
-                               world x max_instances commands whenever chunk_capacity is tightened */
+                               world x (largest max_instances) commands whenever chunk_capacity is tightened */
   uint32_t flags;           /* MIP_OUT_DEVICE, optionally | MIP_OUT_ASYNC */
 } MipShardedOutputs;
 
@@ -384,11 +427,40 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
  * hipImportExternalMemory(OpaqueFd) + hipExternalMemoryGetMappedBuffer. `*out_device_ptr` is then a
  * valid MIP_OUT_DEVICE output pointer (or mip_set_instances_device input) for `size_bytes` bytes.
  * As with cudaImportExternalMemory, a successfully imported fd belongs to the driver: do not use or
- * close it afterwards. Ordering against the Vulkan queue is the caller's (a timeline semaphore,
- * or vkQueueWaitIdle / mip_wait at the hand-over points). */
+ * close it afterwards. Ordering against the Vulkan queue: the semaphore entry points below, or
+ * vkQueueWaitIdle / mip_wait at the hand-over points. */
 int32_t mip_import_external_fd(MipContext* ctx, int32_t fd, uint64_t size_bytes, void** out_device_ptr);
 /* Unmaps a pointer returned by mip_import_external_fd (after mip_wait); mip_destroy releases the rest. */
 int32_t mip_release_external(MipContext* ctx, void* device_ptr);
+
+/* ---- the semaphore half of the same interop -------------------------------------------------------
+ * The reference orders its passes with TIMELINE semaphores, one per frame-graph pass, signalled and
+ * waited with a value derived from the frame number (src/renderer.rs:3757-3861, AutoSemaphores;
+ * `ComputeCull` is the pass this library replaces and the graphics submit waits for it). A semaphore
+ * created with VkExportSemaphoreCreateInfo{handleTypes = OPAQUE_FD_BIT} (+ VkSemaphoreTypeCreateInfo
+ * {TIMELINE}) and exported with vkGetSemaphoreFdKHR is imported here with hipImportExternalSemaphore;
+ * the library then takes the place of the ComputeCull submit:
+ *
+ *   mip_wait_external(ctx, sem_prev, value)   the stream the NEXT frame will run on waits, on the device,
+ *                                             until the semaphore reaches `value` (the reader of the
+ *                                             buffers this frame overwrites has finished)
+ *   mip_run(ctx, frame, outs | MIP_OUT_ASYNC)
+ *   mip_signal_external(ctx, sem_cull, value) enqueued behind the frame that was issued LAST: the
+ *                                             semaphore reaches `value` when its kernels have finished
+ *
+ * and the graphics submit lists sem_cull/value as a wait semaphore: no host wait per frame.
+ * kind: MIP_SEMAPHORE_TIMELINE (what the reference uses) or MIP_SEMAPHORE_BINARY (`value` ignored).
+ * As with memory, a successfully imported fd belongs to the driver. Errors: MIP_ERR_INVALID_ARGUMENT for
+ * a bad fd / kind / a handle this context did not import; MIP_ERR_DEVICE with the runtime's message when
+ * HIP refuses the handle. */
+#define MIP_SEMAPHORE_BINARY 0u
+#define MIP_SEMAPHORE_TIMELINE 1u
+typedef struct MipExternalSemaphore MipExternalSemaphore; /* opaque */
+int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t kind, MipExternalSemaphore** out_semaphore);
+int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value);
+int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value);
+/* After mip_wait; mip_destroy releases the rest. */
+int32_t mip_release_external_semaphore(MipContext* ctx, MipExternalSemaphore* semaphore);
 
 const char* mip_last_error(const MipContext* ctx);
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out);

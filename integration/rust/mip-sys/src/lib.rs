@@ -8,10 +8,19 @@ pub const MIP_OK: i32 = 0;
 pub const MIP_OUT_HOST: u32 = 0;
 pub const MIP_OUT_DEVICE: u32 = 1;
 pub const MIP_OUT_ASYNC: u32 = 2;
+pub const MIP_OUT_WIRE: u32 = 4;
+pub const MIP_SEMAPHORE_BINARY: u32 = 0;
+pub const MIP_SEMAPHORE_TIMELINE: u32 = 1;
 pub const MIP_MAX_LODS: usize = 6;
 
 #[repr(C)]
 pub struct MipContext {
+    _private: [u8; 0],
+}
+
+/// Opaque handle of an imported external semaphore (mip_import_external_semaphore_fd).
+#[repr(C)]
+pub struct MipExternalSemaphore {
     _private: [u8; 0],
 }
 
@@ -106,6 +115,9 @@ extern "C" {
     pub fn mip_wait(ctx: *mut MipContext) -> i32;
     pub fn mip_merge_draw_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
                                 chunk_capacity: u32, out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+    /// The same merge over chunks in the wire form (MIP_OUT_WIRE: 8-byte records, expanded against the mesh table).
+    pub fn mip_merge_wire_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
+                                chunk_capacity: u32, out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
     /// Shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, light-major, into device memory.
     pub fn mip_light_draw_lists(ctx: *mut MipContext, light_pos_xyz: *const f32, n_lights: u32, first_instance_base: u32,
                                 out_cmds: *mut c_void, async_: i32) -> i32;
@@ -123,6 +135,13 @@ extern "C" {
     /// Row f-2: map an fd exported with vkGetMemoryFdKHR (OPAQUE_FD; a dma-buf on amdgpu) into the HIP device.
     pub fn mip_import_external_fd(ctx: *mut MipContext, fd: i32, size_bytes: u64, out_device_ptr: *mut *mut c_void) -> i32;
     pub fn mip_release_external(ctx: *mut MipContext, device_ptr: *mut c_void) -> i32;
+    /// Row f-2, the semaphore half: a timeline semaphore exported with vkGetSemaphoreFdKHR (renderer.rs:3757-3861).
+    pub fn mip_import_external_semaphore_fd(ctx: *mut MipContext, fd: i32, kind: u32, out_semaphore: *mut *mut MipExternalSemaphore) -> i32;
+    /// The next frame's stream waits on the device until the semaphore reaches `value`.
+    pub fn mip_wait_external(ctx: *mut MipContext, semaphore: *mut MipExternalSemaphore, value: u64) -> i32;
+    /// Signals `value` behind the frame issued last.
+    pub fn mip_signal_external(ctx: *mut MipContext, semaphore: *mut MipExternalSemaphore, value: u64) -> i32;
+    pub fn mip_release_external_semaphore(ctx: *mut MipContext, semaphore: *mut MipExternalSemaphore) -> i32;
     pub fn mip_last_error(ctx: *const MipContext) -> *const c_char;
     pub fn mip_instance_count(ctx: *const MipContext) -> u32;
 }

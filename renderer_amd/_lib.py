@@ -22,12 +22,19 @@ MIP_CFG_ORDERED_TILES = 0x2
 MIP_OUT_HOST = 0x0
 MIP_OUT_DEVICE = 0x1
 MIP_OUT_ASYNC = 0x2
+MIP_OUT_WIRE = 0x4
+MIP_WIRE_BLOCK_COMMANDS = 256
+MIP_WIRE_BLOCK_HEADER_BYTES = 16
+MIP_WIRE_RECORD_BYTES = 8
+MIP_WIRE_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_RECORD_BYTES
 MIP_MAX_LODS = 6
+MIP_SEMAPHORE_BINARY = 0
+MIP_SEMAPHORE_TIMELINE = 1
 
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_merge_wire_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_import_external_semaphore_fd", "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -99,6 +106,7 @@ class MipTimings(C.Structure):
         ("graph_frames", C.c_uint64),
         ("graph_records", C.c_uint64),
         ("sharded_retries", C.c_uint64),
+        ("sharded_bytes_sent", C.c_uint64),
         ("general_launches", C.c_uint64),
     ]
 
@@ -155,6 +163,8 @@ def load_library():
     lib.mip_wait.restype = C.c_int32
     lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
     lib.mip_merge_draw_lists.restype = C.c_int32
+    lib.mip_merge_wire_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
+    lib.mip_merge_wire_lists.restype = C.c_int32
     lib.mip_light_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32]
     lib.mip_light_draw_lists.restype = C.c_int32
     lib.mip_set_skeleton.argtypes = [vp, vp, vp, vp, C.c_uint32]
@@ -177,6 +187,14 @@ def load_library():
     lib.mip_import_external_fd.restype = C.c_int32
     lib.mip_release_external.argtypes = [vp, vp]
     lib.mip_release_external.restype = C.c_int32
+    lib.mip_import_external_semaphore_fd.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(vp)]
+    lib.mip_import_external_semaphore_fd.restype = C.c_int32
+    lib.mip_wait_external.argtypes = [vp, vp, C.c_uint64]
+    lib.mip_wait_external.restype = C.c_int32
+    lib.mip_signal_external.argtypes = [vp, vp, C.c_uint64]
+    lib.mip_signal_external.restype = C.c_int32
+    lib.mip_release_external_semaphore.argtypes = [vp, vp]
+    lib.mip_release_external_semaphore.restype = C.c_int32
     lib.mip_last_error.argtypes = [vp]
     lib.mip_last_error.restype = C.c_char_p
     lib.mip_get_timings.argtypes = [vp, C.POINTER(MipTimings)]

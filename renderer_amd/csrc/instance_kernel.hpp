@@ -95,6 +95,7 @@ struct KernelArgs {
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
   uint32_t n_meshes;            // mesh-table entries
+  uint32_t wire;                // != 0: `cmds` receives the wire form of the list (MIP_OUT_WIRE; wire_copy_out below)
   // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
   // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
   // without re-recording: the host refreshes the ring with one copy per replay
@@ -131,7 +132,18 @@ constexpr uint32_t kFrameWords = 32;
 // equivalence exhaustively around 100).
 constexpr float kLodDistSqThreshold = 100.00000762939453125f;  // 100 + 2^-17
 
-constexpr uint32_t kErrTimeout = 1u;
+// Device -> host error word(s), host-mapped memory. Every kind of error has a word of its own (plain stores from
+// different kernels of one frame must not overwrite each other: a timeout in the shard kernel followed by an
+// overflow seen by the merge kernel are BOTH needed by the host); the host ORs the words together.
+constexpr uint32_t kErrTimeout = 1u;         // word 0: a bounded prefix wait of the instance / views kernel expired
+constexpr uint32_t kErrChunkOverflow = 2u;   // word 1: a gathered shard list is longer than the exchanged chunk
+constexpr uint32_t kErrIndexOverflow = 4u;   // word 2: culled_index_buffer too small
+constexpr uint32_t kErrWireRecord = 8u;      // word 3: a wire record names a mesh outside the table
+constexpr uint32_t kErrPartsTimeout = 16u;   // word 4: a bounded wait of the triangle parts kernel expired
+constexpr uint32_t kErrWords = 5;
+__device__ __forceinline__ void raise_error(uint32_t* error_flag, uint32_t bit) {
+  __hip_atomic_store(error_flag + (31 - __builtin_clz(bit)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---------------------------------------------------------------------------------------
 // wave64 helpers
@@ -517,7 +529,7 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
       __hip_atomic_store(p + 1, ((unsigned long long)a.epoch << 32) | base_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
-    if (lane == 0) __hip_atomic_store(a.error_flag, kErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) raise_error(a.error_flag, kErrTimeout);
     base_count = 0;
     base_sum = 0;
   }
@@ -560,12 +572,16 @@ __device__ __forceinline__ float separable_bound(const float (&r)[3][3], float p
 // launched as mip_instance_pipeline_kernel<.., .., kGeneral = false>.
 struct CensusArgs {
   const float* pos; const float4* rot; const float* scale;
+  const uint32_t* mesh_id;  // or null: ids not checked
+  uint32_t n_meshes;
   uint32_t first, count;
   float box_abs;  // largest sum of |box coordinates| over the mesh table
-  uint32_t* out;  // += number of instances that need the kernel with the fall-back paths
+  uint32_t* out;  // [0] += number of instances that need the kernel with the fall-back paths
+                  // [1] += number of instances whose mesh id is outside the table (the frame kernel gathers
+                  //         meshes[mesh_id] unchecked: such an upload is refused, as mip_set_instances refuses it on the host)
 };
 __global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusArgs a) {
-  uint32_t bad = 0;
+  uint32_t bad = 0, bad_id = 0;
   for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.count; k += gridDim.x * 256u) {
     const size_t i = (size_t)a.first + k;
     const float4 q = a.rot[i];
@@ -574,9 +590,31 @@ __global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusAr
     const float px = a.pos[3 * i], py = a.pos[3 * i + 1], pz = a.pos[3 * i + 2], sc = a.scale[i];
     const bool ok = finite_magnitude(r, px, py, pz, sc) < kFiniteLimit && separable_bound(r, px, py, pz, sc, a.box_abs) < kSeparableLimit;
     bad += ok ? 0u : 1u;
+    if (a.mesh_id) bad_id += a.mesh_id[i] >= a.n_meshes ? 1u : 0u;
   }
   bad = wave_sum(bad);
+  bad_id = wave_sum(bad_id);
   if ((threadIdx.x & 63u) == 0u && bad) atomicAdd(a.out, bad);
+  if ((threadIdx.x & 63u) == 0u && bad_id) atomicAdd(a.out + 1, bad_id);
+}
+
+// The wire form of a shard's draw list (include/mi_instance_pipeline.h, MIP_OUT_WIRE): blocks of 256 8-byte records
+// {firstInstance, mesh | lod << 31}, each block behind a 16-byte header whose first word is the firstIndex of the
+// block's first command. 8.06 B per command instead of 20 through the all-gather; mip_merge_wire_lists_kernel
+// (merge_kernel.hpp) expands it against the replicated mesh table.
+constexpr uint32_t kWireBlockCmds = 256, kWireBlockHeaderWords = 4, kWireBlockWords = kWireBlockHeaderWords + 2 * kWireBlockCmds;
+
+// Copy-out of a tile's `tile_count` staged commands (LDS, kCmdLdsWords each: [2] tile-relative firstIndex,
+// [4] firstInstance, [5] mesh | lod << 31) as wire records at list positions base_count .. ; run by one wave.
+__device__ __forceinline__ void wire_copy_out(uint32_t* body, const uint32_t* s_cmd, uint32_t lane, uint32_t base_count,
+                                              uint32_t first_index_add, uint32_t tile_count) {
+  for (uint32_t k = lane; k < tile_count; k += 64u) {
+    const uint32_t g = base_count + k, block = g / kWireBlockCmds, slot = g % kWireBlockCmds;
+    uint32_t* b = body + (size_t)block * kWireBlockWords;
+    const uint32_t* c = &s_cmd[k * kCmdLdsWords];
+    *reinterpret_cast<uint2*>(b + kWireBlockHeaderWords + 2u * slot) = make_uint2(c[4], c[5]);
+    if (slot == 0u) *reinterpret_cast<uint4*>(b) = make_uint4(c[2] + first_index_add, 0u, 0u, 0u);
+  }
 }
 
 // Tile aggregate assembled in LDS by the four waves: {Σ index_len : 32 | arrivals : 8 | - : 8 | count : 16}.
@@ -590,7 +628,8 @@ constexpr uint32_t kAggArrivalShift = 24;
 // kBoxOverride: every instance brings its own mesh-space box (KernelArgs.box_override; the skinned
 // extension).
 // kGeneral: the kernel carries the literal arithmetic chain for non-finite inputs (taken per wave).
-// That path costs 16 VGPRs (80 against 64: 6 against 8 waves per SIMD) whether it runs or not, so
+// That path costs 16-20 VGPRs (80-84 against 64: compiled for MIP_MIN_WAVES_PER_SIMD = 5 waves per SIMD against 8)
+// whether it runs or not, so
 // the host launches <.., .., false> whenever its upload-time census found every instance finite
 // (mesh-table boxes always are); a per-instance box override may be non-finite, so it implies kGeneral.
 // kOrder: what a workgroup does between its arithmetic and its exit (both orders produce identical bytes).
@@ -841,7 +880,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
       uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
       c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = first_instance_base + i;
-      c[5] = far_lod ? md.z : md.y;
+      c[5] = a.wire ? (mesh | (far_lod ? 0x80000000u : 0u)) : (far_lod ? md.z : md.y);
     }
     __syncthreads();
     MIP_STAMP(3);
@@ -854,6 +893,12 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     MIP_STAMP(4);
     const uint32_t first_index_add = base_sum + first_index_base;
+    if (a.wire) {
+      wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
+      store_aabb();
+      MIP_STAMP(5);
+      return;
+    }
     uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
     const uint32_t words = tile_count * kCmdWords;
     for (uint32_t j = lane; j < words; j += 64u) {
@@ -897,7 +942,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
     c[3] = md.x;                                              // vertexOffset, :66
     c[4] = first_instance_base + i;                         // firstInstance = draw_index, :64
-    c[5] = far_lod ? md.z : md.y;                             // push constant indexOffset, cull_pipeline.rs:552
+    c[5] = a.wire ? (mesh | (far_lod ? 0x80000000u : 0u))     // wire form: the record's second word
+                  : (far_lod ? md.z : md.y);                  // push constant indexOffset, cull_pipeline.rs:552
   }
   __syncthreads();  // commands, staged matrices and visibility words of every wave are in LDS
   MIP_STAMP(3);
@@ -936,6 +982,12 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   // ---- coalesced copy-out of the tile's commands ----
   const uint32_t first_index_add = base_sum + first_index_base;
+  if (a.wire) {
+    wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
+    store_aabb();
+    MIP_STAMP(5);
+    return;
+  }
   uint32_t* out = a.cmds + (size_t)base_count * kCmdWords;
   const uint32_t words = tile_count * kCmdWords;
   for (uint32_t j = lane; j < words; j += 64u) {

@@ -21,8 +21,6 @@ struct MergeArgs {
   uint32_t* error_flag; // host-mapped
 };
 
-constexpr uint32_t kErrChunkOverflow = 2u;
-
 constexpr uint32_t kMaxMergeChunks = 64;
 
 __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeArgs a) {
@@ -38,7 +36,7 @@ __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeAr
       uint32_t count = h[0];
       if (count > capacity) {  // the shard emitted more than the exchanged chunk holds
         count = capacity;
-        if (blockIdx.x == 0) __hip_atomic_store(a.error_flag, kErrChunkOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0) raise_error(a.error_flag, kErrChunkOverflow);
       }
       s_count_base[k] = c;
       s_index_base[k] = s;
@@ -63,6 +61,100 @@ __global__ __launch_bounds__(256) void mip_merge_draw_lists_kernel(const MergeAr
     uint32_t v = body[(cmd - s_count_base[chunk]) * kCmdWords + field];
     if (field == 2u) v += s_index_base[chunk];
     a.out_cmds[j] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// the same merge over chunks in the WIRE form (MIP_OUT_WIRE; instance_kernel.hpp wire_copy_out)
+// ---------------------------------------------------------------------------------------
+// chunk = [32-B header {count, index total} | blocks of {16-B header: firstIndex of the block's first command |
+// 256 x {firstInstance, mesh | lod << 31}}]. One workgroup expands one block at a time: each thread one record ->
+// indexCount / vertexOffset from the mesh table, firstIndex = block header + the index_len of the records in front
+// of it in the block (DPP scan per wave + the wave totals in LDS) + the index totals of the earlier chunks; the 256
+// commands leave through LDS so that the 20-byte records are written as contiguous dwords.
+
+struct MergeWireArgs {
+  const unsigned char* chunks;
+  unsigned long long stride;
+  uint32_t n_chunks;
+  uint32_t capacity;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+  uint32_t* error_flag;
+  const MeshEntry* meshes;
+  const MeshDraw* mesh_draw;
+  uint32_t n_meshes;
+};
+
+__global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWireArgs a) {
+  static_assert(kWireBlockCmds == 256, "one thread per record of a block");
+  __shared__ uint32_t s_count_base[kMaxMergeChunks + 1], s_index_base[kMaxMergeChunks + 1], s_block_base[kMaxMergeChunks + 1];
+  __shared__ uint32_t s_wave_total[4];
+  __shared__ uint32_t s_out[kWireBlockCmds * kCmdWords];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) {
+    uint32_t c = 0, s = 0, nb = 0;
+    const uint32_t fits = (uint32_t)((a.stride - 32u) / (kWireBlockWords * 4u)) * kWireBlockCmds;
+    const uint32_t capacity = a.capacity < fits ? a.capacity : fits;
+    for (uint32_t k = 0; k < a.n_chunks; ++k) {
+      const uint32_t* h = reinterpret_cast<const uint32_t*>(a.chunks + k * a.stride);
+      uint32_t count = h[0];
+      if (count > capacity) {  // the shard emitted more than the exchanged chunk holds
+        count = capacity;
+        if (blockIdx.x == 0) raise_error(a.error_flag, kErrChunkOverflow);
+      }
+      s_count_base[k] = c;
+      s_index_base[k] = s;
+      s_block_base[k] = nb;
+      c += count;
+      s += h[1];
+      nb += (count + kWireBlockCmds - 1u) / kWireBlockCmds;
+    }
+    s_count_base[a.n_chunks] = c;
+    s_index_base[a.n_chunks] = s;
+    s_block_base[a.n_chunks] = nb;
+    if (blockIdx.x == 0) {
+      a.out_count[0] = c;
+      a.out_count[1] = s;
+    }
+  }
+  __syncthreads();
+  const uint32_t total_blocks = s_block_base[a.n_chunks];
+  uint32_t chunk = 0;
+  for (uint32_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+    while (blk >= s_block_base[chunk + 1]) ++chunk;  // blk only grows
+    const uint32_t b = blk - s_block_base[chunk];
+    const uint32_t chunk_count = s_count_base[chunk + 1] - s_count_base[chunk];
+    const uint32_t in_block = chunk_count - b * kWireBlockCmds < kWireBlockCmds ? chunk_count - b * kWireBlockCmds : kWireBlockCmds;
+    const uint32_t* body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kWireBlockWords;
+    const bool valid = tid < in_block;
+    uint2 rec = make_uint2(0u, 0u);
+    if (valid) rec = *reinterpret_cast<const uint2*>(body + kWireBlockHeaderWords + 2u * tid);
+    uint32_t mesh = rec.y & 0x7fffffffu;
+    if (mesh >= a.n_meshes) {  // never follow a corrupt record out of the table
+      if (valid) raise_error(a.error_flag, kErrWireRecord);
+      mesh = 0u;
+    }
+    uint32_t len = 0u;
+    int32_t vertex_offset = 0;
+    if (valid && a.n_meshes) {
+      len = (rec.y >> 31) ? a.meshes[mesh].len1 : a.meshes[mesh].len0;
+      vertex_offset = a.mesh_draw[mesh].vertex_offset;
+    }
+    const uint32_t incl = wave_inclusive_scan(len);
+    if (lane == 63u) s_wave_total[wave] = incl;
+    __syncthreads();  // wave totals in; also: the previous block's copy-out has read s_out
+    uint32_t before = body[0] + s_index_base[chunk] + (incl - len);
+#pragma unroll
+    for (uint32_t w = 0; w < 3; ++w)
+      if (w < wave) before += s_wave_total[w];
+    if (valid) {
+      uint32_t* c = &s_out[tid * kCmdWords];
+      c[0] = len; c[1] = 1u; c[2] = before; c[3] = (uint32_t)vertex_offset; c[4] = rec.x;
+    }
+    __syncthreads();
+    uint32_t* out = a.out_cmds + ((size_t)s_count_base[chunk] + (size_t)b * kWireBlockCmds) * kCmdWords;
+    for (uint32_t j = tid; j < in_block * kCmdWords; j += 256u) out[j] = s_out[j];
   }
 }
 

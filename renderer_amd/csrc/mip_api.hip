@@ -45,6 +45,7 @@ struct MipContext {
     uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
     unsigned long long* d_part_status = nullptr;  //                small frames: one granule per (command, part)
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
+    bool parts_dirty = false;                //                     a parts launch timed out: clear the granules before the next one
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
     // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
     // refreshed before every replay from one of two pinned staging halves
@@ -135,6 +136,8 @@ struct MipContext {
   // native sharded exchange (mip_comm_*, mip_run_sharded)
   ncclComm_t comm = nullptr;
   uint32_t comm_rank = 0, comm_world = 0;
+  uint32_t shard_cap_max = 0;  // largest max_instances over the ranks: what every rank sizes its chunks by
+  bool shard_wire = true;      // mip_run_sharded exchanges the wire form of the lists (MIP_TUNE_SHARD_WIRE=0: 20-byte commands)
   uint32_t* d_send = nullptr;  // this rank's chunk, sized for max_instances commands
   uint32_t* d_recv = nullptr;  // world chunks
   // the last sharded frame, kept so that a tightened chunk that overflowed can be re-gathered at full capacity
@@ -144,6 +147,10 @@ struct MipContext {
   // imported external memory (mip_import_external_fd)
   struct External { hipExternalMemory_t mem; void* ptr; };
   std::vector<External> externals;
+  // imported external semaphores (mip_import_external_semaphore_fd); the handle given out is the entry's address
+  struct ExternalSemaphore { hipExternalSemaphore_t sem; uint32_t kind; };
+  std::vector<ExternalSemaphore*> semaphores;
+  uint32_t last_slot = 0;  // slot of the frame issued last (mip_signal_external goes behind it)
   char err[512] = {0};
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* d_stamps = nullptr;
@@ -193,27 +200,48 @@ int32_t ensure_staging(MipContext* ctx, const MipOutputs* out) {
 
 int32_t repair_sharded_overflow(MipContext* ctx);
 
-// Reads and clears the device-visible error word after the stream has drained.
+// Reads and clears the device-visible error words (one per kind, instance_kernel.hpp) after the streams have drained.
+//
+// A sharded frame may need a COLLECTIVE repair (the all-gather + merge repeated at full capacity when a tightened
+// chunk overflowed). Whether it does is decided from the gathered headers alone — kErrChunkOverflow is raised by the
+// merge kernel, which sees the same headers on every rank — and never from anything only this rank knows: a rank
+// whose own shard kernel timed out (half-written chunk, garbage header, likely an "overflow" everywhere) still takes
+// part in the repair its peers are entering, and reports its local error afterwards. Returning before the repair
+// (round 2 did) left the other ranks blocked in ncclAllGather for good.
 int32_t check_device_error(MipContext* ctx) {
-  const uint32_t e = *(volatile uint32_t*)ctx->h_error;
-  if (e) {
-    *(volatile uint32_t*)ctx->h_error = 0;
-    if (e & mip::kErrTimeout) {
-      // the frame's prefix state is half-written: clear it before the next launch, and from now on
-      // number the tiles from a counter, which cannot stall on the order workgroups start in
-      for (auto& sl : ctx->slots) sl.status_dirty = true;
-      for (auto& sl : ctx->view_states) sl.status_dirty = true;
-      ctx->ordered_tiles = true;
-      ctx->graph_generation++;
-      return fail(ctx, MIP_ERR_TIMEOUT,
-                  "prefix wait expired (an earlier tile never published); outputs invalid; the context now uses ordered tiles");
-    }
-    if (e & mip::kErrIndexOverflow)
-      return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
-    if (int32_t rc = repair_sharded_overflow(ctx)) return rc;
-    return MIP_OK;
+  uint32_t e = 0;
+  for (uint32_t k = 0; k < mip::kErrWords; ++k) {
+    e |= ((volatile uint32_t*)ctx->h_error)[k];
+    ((volatile uint32_t*)ctx->h_error)[k] = 0;
   }
-  return MIP_OK;
+  if (!e) return MIP_OK;
+  int32_t repair_rc = MIP_OK;
+  if (e & mip::kErrChunkOverflow) repair_rc = repair_sharded_overflow(ctx);
+  if (e & mip::kErrTimeout) {
+    // the frame's prefix state is half-written: clear it before the next launch, and from now on
+    // number the tiles from a counter, which cannot stall on the order workgroups start in
+    for (auto& sl : ctx->slots) sl.status_dirty = true;
+    for (auto& sl : ctx->view_states) sl.status_dirty = true;
+    ctx->ordered_tiles = true;
+    ctx->graph_generation++;
+    return fail(ctx, MIP_ERR_TIMEOUT,
+                "prefix wait expired (an earlier tile never published); outputs invalid; the context now uses ordered tiles");
+  }
+  if (e & mip::kErrPartsTimeout) {
+    // mip_triangle_cull_parts_kernel assumes its whole grid is resident (a part waits for the earlier parts of its
+    // command, which other workgroups own); another tenant on the GPU can break that. Ordered tiles do not help
+    // this kernel: stop using it — the workgroup-per-command kernel has no cross-workgroup wait.
+    ctx->tri_parts_max = 0;
+    for (auto& sl : ctx->slots) sl.parts_dirty = true;
+    return fail(ctx, MIP_ERR_TIMEOUT,
+                "a part of a command waited in vain for an earlier part (the parts kernel was not resident as a whole); outputs "
+                "invalid; the context now culls triangles with one workgroup per command");
+  }
+  if (e & mip::kErrIndexOverflow)
+    return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
+  if (e & mip::kErrWireRecord)
+    return fail(ctx, MIP_ERR_DEVICE, "a wire record names a mesh outside this context's mesh table (corrupt chunk, or the ranks hold different tables)");
+  return repair_rc;
 }
 
 struct RcclApi {
@@ -282,22 +310,29 @@ FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool t
   return pick_order<false, false>(ctx->ordered_tiles, order);
 }
 
-// Number of instances of [first, first + count) of the resident columns that fail the finite test.
-// Synchronous (uploads are): one small kernel and a 4-byte read-back on the upload stream.
-int32_t census(MipContext* ctx, uint32_t first, uint32_t count, uint32_t* out) {
+// Number of instances of [first, first + count) of the resident columns that fail the finite test, and (bad_ids != null)
+// how many of them name a mesh outside a table of `m` entries.
+// Synchronous (uploads are): one small kernel and an 8-byte read-back on the upload stream.
+int32_t census(MipContext* ctx, uint32_t first, uint32_t count, uint32_t* out, uint32_t* bad_ids = nullptr, uint32_t m = 0) {
   *out = 0;
+  if (bad_ids) *bad_ids = 0;
   if (!count) return MIP_OK;
-  MIP_HIP(ctx, hipMemsetAsync(ctx->d_census, 0, 4, ctx->stream));
+  MIP_HIP(ctx, hipMemsetAsync(ctx->d_census, 0, 8, ctx->stream));
   mip::CensusArgs c{};
   c.pos = ctx->d_pos; c.rot = ctx->d_rot; c.scale = ctx->d_scale;
+  c.mesh_id = bad_ids ? ctx->d_mesh_id : nullptr;
+  c.n_meshes = m;
   c.first = first; c.count = count; c.out = ctx->d_census;
   c.box_abs = ctx->box_abs;
   uint32_t blocks = (count + 255u) / 256u;
   if (blocks > 2048u) blocks = 2048u;
   hipLaunchKernelGGL(mip::mip_count_nonfinite_kernel, dim3(blocks), dim3(256), 0, ctx->stream, c);
   MIP_HIP(ctx, hipGetLastError());
-  MIP_HIP(ctx, hipMemcpyAsync(out, ctx->d_census, 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t both[2] = {0, 0};
+  MIP_HIP(ctx, hipMemcpyAsync(both, ctx->d_census, 8, hipMemcpyDeviceToHost, ctx->stream));
   MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = both[0];
+  if (bad_ids) *bad_ids = both[1];
   return MIP_OK;
 }
 
@@ -326,6 +361,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
+  a.wire = (device_out && (out->flags & MIP_OUT_WIRE)) ? 1u : 0u;
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
@@ -399,6 +435,11 @@ int32_t validate_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
   const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
   if ((out->flags & MIP_OUT_ASYNC) && !device_out)
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
+  if (out->flags & MIP_OUT_WIRE) {
+    if (!device_out || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs MIP_OUT_DEVICE and draw_cmds");
+    if (out->culled_index_buffer) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE cannot carry the per-triangle stage's indexCount");
+    if (ctx->m > 0x7fffffffu) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs mesh ids below 2^31");
+  }
   if (out->culled_index_buffer) {
     if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
     if (!ctx->have_geometry) return fail(ctx, MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
@@ -425,6 +466,11 @@ void free_all(MipContext* ctx) {
   drop_graphs(ctx);
   for (auto& e : ctx->externals) (void)hipDestroyExternalMemory(e.mem);  // unmaps the buffer as well
   ctx->externals.clear();
+  for (auto* e : ctx->semaphores) {
+    (void)hipDestroyExternalSemaphore(e->sem);
+    delete e;
+  }
+  ctx->semaphores.clear();
   (void)hipFree(ctx->d_pos);
   (void)hipFree(ctx->d_rot);
   (void)hipFree(ctx->d_scale);
@@ -515,7 +561,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_id, cap * 4));
     MIP_HIP(ctx, hipMalloc(&ctx->d_meshes, mcap * sizeof(mip::MeshEntry)));
     MIP_HIP(ctx, hipMalloc(&ctx->d_mesh_draw, mcap * sizeof(mip::MeshDraw)));
-    MIP_HIP(ctx, hipMalloc(&ctx->d_census, 4));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_census, 8));
     ctx->cu_count = prop.multiProcessorCount;
     const size_t tiles_cap = tiles_for((uint32_t)cap);
     // smallest group the kernel may pick is 16 tiles (group_shift 4)
@@ -593,6 +639,13 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
   }
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
+  if (ctx->have_instances && ctx->have_meshes && m < ctx->m) {
+    // a smaller table: the resident mesh ids (validated against the old one) must still be inside it
+    uint32_t bad = 0, bad_ids = 0;
+    if (int32_t rc = census(ctx, 0, ctx->n, &bad, &bad_ids, m)) return rc;
+    if (bad_ids)
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u resident instance(s) name a mesh >= the new table's %u entries; table unchanged", bad_ids, m);
+  }
   if (m) {
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice, ctx->stream));
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_draw, draw.data(), m * sizeof(mip::MeshDraw), hipMemcpyHostToDevice, ctx->stream));
@@ -680,8 +733,17 @@ static int32_t set_instances_common(MipContext* ctx, const void* pos, const void
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_id, mesh_id, (size_t)n * 4, kind, ctx->stream));
     MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // stream-ordered copies: finished before any slot launches again
   }
-  uint32_t bad = 0;
-  if (int32_t rc = census(ctx, 0, n, &bad)) return rc;
+  uint32_t bad = 0, bad_ids = 0;
+  if (int32_t rc = census(ctx, 0, n, &bad, &bad_ids, ctx->m)) return rc;
+  if (bad_ids) {
+    // the resident columns now hold ids the frame kernel would follow out of the mesh table: nothing is resident
+    ctx->have_instances = false;
+    ctx->n = 0;
+    for (auto& sl : ctx->slots) sl.status_dirty = true;
+    for (auto& sl : ctx->view_states) sl.status_dirty = true;
+    ctx->graph_generation++;
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u instance(s) with a mesh id >= %u meshes; no instances are resident now", bad_ids, ctx->m);
+  }
   if ((bad != 0) != (ctx->nonfinite_instances != 0)) ctx->graph_generation++;  // recorded launches name the other kernel
   ctx->nonfinite_instances = bad;
   if (n != ctx->n) {
@@ -749,6 +811,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
   // Frames rotate over the slots; a slot's stream orders a frame after the frame that last
   // used the same prefix state.
   MipContext::FrameSlot& sl = ctx->slots[ctx->next_slot];
+  ctx->last_slot = ctx->next_slot;
   ctx->next_slot = (ctx->next_slot + 1) % (uint32_t)ctx->slots.size();
   hipStream_t stream = sl.stream;
 
@@ -835,7 +898,9 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
       // The command count lives on the device; the instance count bounds it. Small frames: one
       // 1024-thread workgroup per command; large frames: one wave per command (no barriers).
-      const bool parts = ctx->tri_parts_max && n <= ctx->tri_parts_max && !ctx->tri_block_threads &&
+      // (the parts kernel waits across workgroups and needs its whole grid resident: only while this context runs
+      //  one frame at a time — two slots' launches could each be half resident; see kErrPartsTimeout for other tenants)
+      const bool parts = ctx->tri_parts_max && n <= ctx->tri_parts_max && !ctx->tri_block_threads && ctx->slots.size() == 1 &&
                          ctx->max_lod_tris <= mip::kTriParts * 256u * mip::kTriPartMaxT;
       if (parts) {
         // small frames: 16 parts per command, handed out in order by a ticket counter (triangle_kernels.hpp)
@@ -845,7 +910,8 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
           MIP_HIP(ctx, hipMemsetAsync(sl.d_part_status, 0, cap_cmds * mip::kTriParts * 8, stream));
           sl.tri_epoch = 0;
         }
-        if (sl.tri_epoch == 0xffffffffu) {  // tag wrap: start over on a cleared array
+        if (sl.tri_epoch == 0xffffffffu || sl.parts_dirty) {  // tag wrap (or a timed-out launch): start over on a cleared array
+          sl.parts_dirty = false;
           MIP_HIP(ctx, hipMemsetAsync(sl.d_part_status, 0, cap_cmds * mip::kTriParts * 8, stream));
           sl.tri_epoch = 0;
         }
@@ -1423,6 +1489,69 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
   return check_device_error(ctx);
 }
 
+static uint64_t wire_stride_bytes(uint64_t capacity) {
+  return (sizeof(MipShardHeader) + MIP_WIRE_BODY_BYTES(capacity) + 255) / 256 * 256;
+}
+
+static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                                  uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count) {
+  static_assert(MIP_WIRE_BLOCK_COMMANDS == mip::kWireBlockCmds && MIP_WIRE_BLOCK_BYTES == mip::kWireBlockWords * 4u &&
+                MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u, "wire layout: header and kernels agree");
+  mip::MergeWireArgs a{};
+  a.chunks = (const unsigned char*)chunks;
+  a.stride = chunk_stride_bytes;
+  a.n_chunks = n_chunks;
+  a.capacity = chunk_capacity;
+  a.out_cmds = (uint32_t*)out_cmds;
+  a.out_count = out_count;
+  a.error_flag = ctx->d_error;
+  a.meshes = ctx->d_meshes;
+  a.mesh_draw = ctx->d_mesh_draw;
+  a.n_meshes = ctx->m;
+  // one workgroup expands one block of 256 records at a time; sized for the blocks the chunks can hold
+  const uint64_t max_blocks = ((uint64_t)chunk_capacity + mip::kWireBlockCmds - 1) / mip::kWireBlockCmds * n_chunks;
+  uint32_t blocks = max_blocks > 256u * 8u ? 256u * 8u : (uint32_t)max_blocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mip::mip_merge_wire_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+  MIP_HIP(ctx, hipGetLastError());
+  return MIP_OK;
+}
+
+int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                             uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (!chunks || !out_cmds || !out_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (!ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "wire records are expanded against the mesh table: set it first");
+  if (n_chunks == 0 || n_chunks > mip::kMaxMergeChunks)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_chunks %u outside 1..%u", n_chunks, mip::kMaxMergeChunks);
+  if (chunk_stride_bytes < sizeof(MipShardHeader)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad chunk stride");
+  if (chunk_capacity == 0) {  // what the stride holds, in whole blocks
+    const uint64_t fits = (chunk_stride_bytes - sizeof(MipShardHeader)) / MIP_WIRE_BLOCK_BYTES * MIP_WIRE_BLOCK_COMMANDS;
+    chunk_capacity = fits > 0x3fffffffull ? 0x3fffffffu : (uint32_t)fits;
+  }
+  if ((chunk_stride_bytes & 15u) || sizeof(MipShardHeader) + MIP_WIRE_BODY_BYTES(chunk_capacity) > chunk_stride_bytes)
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "a wire chunk for %u commands does not fit a stride of %llu bytes (or the stride is not 16-byte aligned)",
+                chunk_capacity, (unsigned long long)chunk_stride_bytes);
+  if (int32_t rc = bind_device(ctx)) return rc;
+  const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0 && !async;
+  if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (int32_t rc = enqueue_merge_wire(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count)) return rc;
+  if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (async) {
+    ctx->pending_async = true;
+    return MIP_OK;
+  }
+  MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (timing) {
+    float ms = 0.f;
+    MIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->timings.merges += 1;
+    ctx->timings.last_merge_ms = ms;
+    ctx->timings.total_merge_ms += ms;
+  }
+  return check_device_error(ctx);
+}
+
 int32_t mip_comm_unique_id(uint8_t out_id[MIP_COMM_ID_BYTES]) {
   if (!out_id) return MIP_ERR_INVALID_ARGUMENT;
   const RcclApi* r = rccl();
@@ -1455,9 +1584,29 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
   }
   ctx->comm_rank = rank;
   ctx->comm_world = world;
-  const size_t cap = ctx->max_instances ? ctx->max_instances : 1;
-  const size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;
+  if (const char* env = std::getenv("MIP_TUNE_SHARD_WIRE")) ctx->shard_wire = std::atoi(env) != 0;  // A/B and tests: 0 = exchange 20-byte commands
   const int32_t rc = [&]() -> int32_t {
+    // Chunks must have the same size on every rank, but ranks may have been created for different capacities (the
+    // last of ceil(N/R)-sized shards is shorter): one 4-byte all-gather settles on the largest max_instances.
+    uint32_t* d_caps = nullptr;
+    MIP_HIP(ctx, hipMalloc(&d_caps, (size_t)(world + 1) * 4));
+    const uint32_t mine = ctx->max_instances ? ctx->max_instances : 1u;
+    std::vector<uint32_t> caps(world, 0u);
+    const int32_t rc2 = [&]() -> int32_t {
+      MIP_HIP(ctx, hipMemcpyAsync(d_caps + world, &mine, 4, hipMemcpyHostToDevice, ctx->stream));
+      const ncclResult_t r2 = r->all_gather(d_caps + world, d_caps, 1, ncclUint32, ctx->comm, ctx->stream);
+      if (r2 != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", r->get_error_string ? r->get_error_string(r2) : "?");
+      MIP_HIP(ctx, hipMemcpyAsync(caps.data(), d_caps, (size_t)world * 4, hipMemcpyDeviceToHost, ctx->stream));
+      MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return MIP_OK;
+    }();
+    (void)hipFree(d_caps);
+    if (rc2 != MIP_OK) return rc2;
+    ctx->shard_cap_max = mine;
+    for (uint32_t c : caps) ctx->shard_cap_max = c > ctx->shard_cap_max ? c : ctx->shard_cap_max;
+    const size_t cap = ctx->shard_cap_max;
+    size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;  // room for either form of the list
+    if (wire_stride_bytes(cap) > stride) stride = wire_stride_bytes(cap);
     MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
     MIP_HIP(ctx, hipMemsetAsync(ctx->d_send, 0, stride, ctx->stream));
     MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
@@ -1483,7 +1632,15 @@ int32_t mip_comm_destroy(MipContext* ctx) {
 }
 
 static int32_t sharded_gather_and_merge(MipContext* ctx, uint32_t cap, void* out_cmds, uint32_t* out_count) {
+  if (ctx->shard_wire) {  // the list travels as 8-byte records (MIP_OUT_WIRE) and is expanded by the merge
+    const uint64_t stride = wire_stride_bytes(cap);
+    const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
+    if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
+    ctx->timings.sharded_bytes_sent = stride;
+    return enqueue_merge_wire(ctx, ctx->d_recv, ctx->comm_world, stride, cap, out_cmds, out_count);
+  }
   const uint64_t stride = (sizeof(MipShardHeader) + (uint64_t)cap * 20 + 255) / 256 * 256;
+  ctx->timings.sharded_bytes_sent = stride;
   // ONE all-gather of the fixed-size chunks, then the merge — same stream, no host round trip
   const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
   if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
@@ -1495,7 +1652,7 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   if (!frame || !out || !out->draw_cmds || !out->draw_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "frame/out/draw_cmds/draw_count is NULL");
   if (!ctx->comm) return fail(ctx, MIP_ERR_NOT_READY, "mip_comm_init has not been called");
   if (!(out->flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_sharded needs MIP_OUT_DEVICE");
-  const uint32_t cap_max = ctx->max_instances ? ctx->max_instances : 1;
+  const uint32_t cap_max = ctx->shard_cap_max;
   const uint32_t cap = (out->chunk_capacity && out->chunk_capacity < cap_max) ? out->chunk_capacity : cap_max;
   // 1. this rank's shard, written straight into its chunk (the send buffer always holds max_instances commands)
   MipOutputs local{};
@@ -1505,7 +1662,7 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   local.draw_count = ctx->d_send;
   local.draw_index_total = ctx->d_send + 1;
   local.draw_cmds = ctx->d_send + sizeof(MipShardHeader) / 4;
-  local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC;
+  local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC | (ctx->shard_wire ? MIP_OUT_WIRE : 0u);
   // kernel, all-gather and merge are ordered by ONE stream and share one send/receive buffer: a sharded
   // frame always takes frame slot 0 (= ctx->stream), whatever frames_in_flight is. Overlapping sharded
   // frames is done with several contexts (renderer_amd/sharded.py, PipelinedExchange).
@@ -1563,6 +1720,78 @@ int32_t mip_release_external(MipContext* ctx, void* device_ptr) {
   return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a pointer returned by mip_import_external_fd");
 }
 
+static MipContext::ExternalSemaphore* find_semaphore(MipContext* ctx, MipExternalSemaphore* h, size_t* at = nullptr) {
+  for (size_t i = 0; i < ctx->semaphores.size(); ++i)
+    if ((void*)ctx->semaphores[i] == (void*)h) {
+      if (at) *at = i;
+      return ctx->semaphores[i];
+    }
+  return nullptr;
+}
+
+int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t kind, MipExternalSemaphore** out_semaphore) {
+  if (out_semaphore) *out_semaphore = nullptr;
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (fd < 0 || !out_semaphore) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad fd / out pointer");
+  if (kind != MIP_SEMAPHORE_BINARY && kind != MIP_SEMAPHORE_TIMELINE) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "kind %u is neither MIP_SEMAPHORE_BINARY nor MIP_SEMAPHORE_TIMELINE", kind);
+  if (int32_t rc = bind_device(ctx)) return rc;
+  hipExternalSemaphoreHandleDesc hd{};
+  hd.type = kind == MIP_SEMAPHORE_TIMELINE ? hipExternalSemaphoreHandleTypeTimelineSemaphoreFd : hipExternalSemaphoreHandleTypeOpaqueFd;
+  hd.handle.fd = fd;
+  hipExternalSemaphore_t sem = nullptr;
+  const hipError_t e = hipImportExternalSemaphore(&sem, &hd);
+  if (e != hipSuccess || !sem)
+    return fail(ctx, MIP_ERR_DEVICE, "hipImportExternalSemaphore(%s) failed: %s", kind == MIP_SEMAPHORE_TIMELINE ? "TimelineSemaphoreFd" : "OpaqueFd",
+                hipGetErrorString(e));
+  auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind};
+  if (!entry) {
+    (void)hipDestroyExternalSemaphore(sem);
+    return fail(ctx, MIP_ERR_OUT_OF_MEMORY, "out of host memory");
+  }
+  ctx->semaphores.push_back(entry);
+  *out_semaphore = (MipExternalSemaphore*)entry;
+  return MIP_OK;
+}
+
+int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
+  if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  hipExternalSemaphoreWaitParams p{};
+  p.params.fence.value = value;
+  // the stream the NEXT frame will be enqueued on: that frame then starts only when the semaphore has been reached
+  MIP_HIP(ctx, hipWaitExternalSemaphoresAsync(&s->sem, &p, 1, ctx->slots[ctx->next_slot].stream));
+  ctx->pending_async = true;
+  return MIP_OK;
+}
+
+int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
+  if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  hipExternalSemaphoreSignalParams p{};
+  p.params.fence.value = value;
+  // behind the frame that was issued last (its slot's stream)
+  MIP_HIP(ctx, hipSignalExternalSemaphoresAsync(&s->sem, &p, 1, ctx->slots[ctx->last_slot].stream));
+  ctx->pending_async = true;
+  return MIP_OK;
+}
+
+int32_t mip_release_external_semaphore(MipContext* ctx, MipExternalSemaphore* semaphore) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  size_t at = 0;
+  MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore, &at);
+  if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
+  if (int32_t rc = bind_device(ctx)) return rc;
+  if (int32_t rc = sync_all(ctx)) return rc;
+  MIP_HIP(ctx, hipDestroyExternalSemaphore(s->sem));
+  ctx->semaphores.erase(ctx->semaphores.begin() + (long)at);
+  delete s;
+  return MIP_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1578,13 +1807,17 @@ int32_t repair_sharded_overflow(MipContext* ctx) {
                 ctx->comm ? " (more than one sharded frame was in flight: the overflowing one can no longer be re-sent)" : "");
   }
   ctx->sharded_pending = 0;
-  const uint32_t cap_max = ctx->max_instances ? ctx->max_instances : 1;
+  const uint32_t cap_max = ctx->shard_cap_max;
   if (int32_t rc = sharded_gather_and_merge(ctx, cap_max, ctx->sharded_out_cmds, ctx->sharded_out_count)) return rc;
   MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timings.sharded_retries += 1;
-  const uint32_t e = *(volatile uint32_t*)ctx->h_error;
-  *(volatile uint32_t*)ctx->h_error = 0;
-  if (e) return fail(ctx, MIP_ERR_DEVICE, "sharded repair failed (device error word %u)", e);
+  uint32_t e = 0;
+  for (uint32_t k = 0; k < mip::kErrWords; ++k) {
+    if (k == 0 || k == 4) continue;  // a local timeout of the frame itself is reported by the caller (check_device_error)
+    e |= ((volatile uint32_t*)ctx->h_error)[k];
+    ((volatile uint32_t*)ctx->h_error)[k] = 0;
+  }
+  if (e) return fail(ctx, MIP_ERR_DEVICE, "sharded repair failed (device error bits %u)", e);
   return MIP_OK;
 }
 }  // namespace

@@ -35,7 +35,6 @@ struct TriangleArgs {
   float pv[16];
 };
 
-constexpr uint32_t kErrIndexOverflow = 4u;
 
 __device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x, float y, float z, float w, float (&o)[4]) {
 #pragma unroll
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_
     }
     const bool affine = model_is_affine(model, a.geometry_finite);
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
-    if (!fits && lane == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!fits && lane == 0) raise_error(a.error_flag, kErrIndexOverflow);
     const size_t dst_tri = (size_t)first_index / 3u;
     const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
     uint32_t survivors = 0;
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
     }
     const bool affine = model_is_affine(model, a.geometry_finite);
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
-    if (!fits && tid == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!fits && tid == 0) raise_error(a.error_flag, kErrIndexOverflow);
     const size_t dst_tri = (size_t)first_index / 3u;
     const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
     uint32_t survivors = 0, buf = 0;
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
     }
     const bool affine = model_is_affine(model, a.geometry_finite);
     const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
-    if (!fits && tid == 0 && part == 0) __hip_atomic_store(a.error_flag, kErrIndexOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!fits && tid == 0 && part == 0) raise_error(a.error_flag, kErrIndexOverflow);
     const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
 
     // ---- test this part's triangles: triangle t_begin + k*256 + tid in step k, kept in registers ----
@@ -528,7 +527,7 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
         if (++polls > kSpinMinPolls && __builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok && lane == 0) __hip_atomic_store(a.error_flag, kErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!ok && lane == 0) raise_error(a.error_flag, kErrPartsTimeout);
       prefix = ok ? wave_sum(got) : 0u;
       if (lane == 0) s_prefix = prefix;
     }

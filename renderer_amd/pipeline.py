@@ -30,6 +30,12 @@ DRAW_CMD_DTYPE = np.dtype(
 SHARD_HEADER_BYTES = 32
 
 
+def wire_body_bytes(capacity):
+    """MIP_WIRE_BODY_BYTES: whole blocks of 256 8-byte records behind a 16-byte block header."""
+    blocks = (int(capacity) + _lib.MIP_WIRE_BLOCK_COMMANDS - 1) // _lib.MIP_WIRE_BLOCK_COMMANDS
+    return blocks * _lib.MIP_WIRE_BLOCK_BYTES
+
+
 def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0, pv=None):
     f = MipFrame()
     if pv is not None:
@@ -171,10 +177,11 @@ class InstancePipeline:
 
     def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0,
                    draw_index_total=0, world_aabb=0, async_=False, culled_index_buffer=0, culled_index_capacity=0,
-                   tlas_instances=0):
-        """Device pointers in, nothing copied. `frame` from make_frame()."""
+                   tlas_instances=0, wire=False):
+        """Device pointers in, nothing copied. `frame` from make_frame(). wire=True: draw_cmds receives the
+        wire form of the list (MIP_OUT_WIRE)."""
         out = MipOutputs()
-        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0)
+        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0) | (_lib.MIP_OUT_WIRE if wire else 0)
         out.model = model or None
         out.visible_bitmap = visible_bitmap or None
         out.draw_cmds = draw_cmds or None
@@ -241,6 +248,24 @@ class InstancePipeline:
     def release_external(self, ptr):
         self._check(self._lib.mip_release_external(self._ctx, ptr))
 
+    def import_external_semaphore_fd(self, fd, timeline=True):
+        """Imports a semaphore another API exported as an fd (vkGetSemaphoreFdKHR); returns the opaque handle."""
+        h = C.c_void_p()
+        kind = _lib.MIP_SEMAPHORE_TIMELINE if timeline is True else (_lib.MIP_SEMAPHORE_BINARY if timeline is False else int(timeline))
+        self._check(self._lib.mip_import_external_semaphore_fd(self._ctx, int(fd), kind, C.byref(h)))
+        return h.value
+
+    def wait_external(self, semaphore, value=0):
+        """The next frame's stream waits on the device until the semaphore reaches `value`."""
+        self._check(self._lib.mip_wait_external(self._ctx, semaphore, int(value)))
+
+    def signal_external(self, semaphore, value=0):
+        """Signals the semaphore to `value` behind the frame issued last."""
+        self._check(self._lib.mip_signal_external(self._ctx, semaphore, int(value)))
+
+    def release_external_semaphore(self, semaphore):
+        self._check(self._lib.mip_release_external_semaphore(self._ctx, semaphore))
+
     # -- native sharded exchange (RCCL opened by the library itself) --
     @staticmethod
     def comm_unique_id():
@@ -279,6 +304,13 @@ class InstancePipeline:
         """chunk_capacity = commands one chunk may carry (out_cmds has room for n_chunks x that); 0 = what
         the stride holds. A chunk whose header count exceeds it is cut and reported (MIP_ERR_CAPACITY)."""
         self._check(self._lib.mip_merge_draw_lists(self._ctx, chunks_ptr, int(n_chunks),
+                                                   int(chunk_stride_bytes), int(chunk_capacity), out_cmds_ptr,
+                                                   out_count_ptr, 1 if async_ else 0))
+
+    def merge_wire_lists(self, chunks_ptr, n_chunks, chunk_stride_bytes, out_cmds_ptr, out_count_ptr,
+                         async_=False, chunk_capacity=0):
+        """The same merge over chunks in the wire form (MIP_OUT_WIRE), expanded against this context's mesh table."""
+        self._check(self._lib.mip_merge_wire_lists(self._ctx, chunks_ptr, int(n_chunks),
                                                    int(chunk_stride_bytes), int(chunk_capacity), out_cmds_ptr,
                                                    out_count_ptr, 1 if async_ else 0))
 

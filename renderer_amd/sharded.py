@@ -3,9 +3,13 @@ the compacted draw lists (torch.distributed: backend "nccl" = RCCL over xGMI on 
 "gloo" in the CPU tests) followed by a merge that concatenates the shards in rank order and
 rebases firstIndex.
 
-Every rank contributes one fixed-size chunk [MipShardHeader | capacity x 20-B commands]; the
-pipeline kernel writes count / index total / commands straight into that chunk, so a frame is
-kernel -> all_gather_into_tensor -> merge kernel with no host round trip. The capacity
+Every rank contributes one fixed-size chunk [MipShardHeader | the list in its WIRE form: 8-byte
+records {firstInstance, mesh | lod << 31} in blocks of 256 behind a 16-byte block header, 8.06 B
+per command instead of 20 — include/mi_instance_pipeline.h, MIP_OUT_WIRE]; the pipeline kernel
+writes count / index total / records straight into that chunk and the merge kernel expands the
+records against the replicated mesh table, so a frame is kernel -> all_gather_into_tensor ->
+merge kernel with no host round trip. (`wire=False` exchanges the 20-byte commands themselves:
+the round-2 format, kept for A/B runs; the merged list is byte-identical either way.) The capacity
 defaults to the shard size and can be tightened from the counts a previous frame produced
 (`tighten`). A frame that overflows a tightened chunk (the camera moved) is not lost: every rank
 sees the same gathered headers, so every rank's merge reports the overflow, and `complete()`
@@ -18,7 +22,7 @@ with world sizes 2 and 3 under gloo on CPU; N = 2/4/8 numbers come from the roun
 import numpy as np
 
 from ._lib import MipError
-from .pipeline import SHARD_HEADER_BYTES, make_frame
+from .pipeline import SHARD_HEADER_BYTES, make_frame, wire_body_bytes
 
 MIP_ERR_CAPACITY = -4
 
@@ -34,8 +38,8 @@ def shard_range(n_global, world, rank):
     return lo, hi
 
 
-def chunk_stride_bytes(capacity):
-    stride = SHARD_HEADER_BYTES + capacity * CMD_BYTES
+def chunk_stride_bytes(capacity, wire=False):
+    stride = SHARD_HEADER_BYTES + (wire_body_bytes(capacity) if wire else capacity * CMD_BYTES)
     return (stride + 255) // 256 * 256
 
 
@@ -46,7 +50,7 @@ class DrawListExchange:
     renderer_amd.InstancePipeline (the HIP context in the product; the tests inject a
     CPU stand-in so the exchange logic runs under gloo)."""
 
-    def __init__(self, pipe, n_local, world, rank, device, dist=None, torch=None, group=None, capacity=None):
+    def __init__(self, pipe, n_local, world, rank, device, dist=None, torch=None, group=None, capacity=None, wire=True):
         if torch is None:
             import torch
         if dist is None:
@@ -54,51 +58,67 @@ class DrawListExchange:
         self.torch, self.dist, self.group = torch, dist, group
         self.pipe, self.n_local, self.world, self.rank, self.device = pipe, int(n_local), int(world), int(rank), device
         self._on_gpu = getattr(torch.device(device), "type", "cpu") == "cuda"
+        self.wire = bool(wire)
+        # Chunk sizes must be the same on every rank (an all-gather of unequal pieces is a collective mismatch),
+        # but the last shard of ceil(N/R)-sized ranges may be shorter: everything is sized by the LARGEST shard.
+        # One tiny all-reduce at construction (collective: every rank constructs its exchange at the same point).
+        nmax = torch.tensor([self.n_local], dtype=torch.int64, device=device)
+        if self.world > 1:
+            dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
+        self.n_max = int(nmax.item())
         # the kernel may emit up to n_local commands, so the send buffer always has room for all of them
-        self._send_full = torch.zeros(chunk_stride_bytes(self.n_local) // 4, dtype=torch.int32, device=device)
+        self._send_full = torch.zeros(chunk_stride_bytes(self.n_max, self.wire) // 4, dtype=torch.int32, device=device)
         self.merged_count = torch.zeros(2, dtype=torch.int32, device=device)
         self.retries = 0       # frames re-gathered at full capacity after a tightened chunk overflowed
         self._in_flight = 0    # frames issued since the last complete()
-        self.set_capacity(self.n_local if capacity is None else capacity)
+        self.set_capacity(self.n_max if capacity is None else capacity)
 
     def set_capacity(self, capacity):
         torch = self.torch
-        self.capacity = int(min(max(capacity, 0), self.n_local))
-        self.stride = chunk_stride_bytes(self.capacity)
+        self.capacity = int(min(max(capacity, 0), self.n_max))  # the same number on every rank
+        self.stride = chunk_stride_bytes(self.capacity, self.wire)
         words = self.stride // 4
         self.send = self._send_full[:words]
         self.recv = torch.empty(self.world * words, dtype=torch.int32, device=self.device)
         self.merged = torch.empty((max(self.world * self.capacity, 1), 5), dtype=torch.int32, device=self.device)
 
-    def step(self, frame, outs=None, model=0, visible_bitmap=0, world_aabb=0):
-        """One frame on this rank. `outs` (optional) supplies model / bitmap device buffers."""
-        if outs is not None:
-            model = outs.model.data_ptr()
-            visible_bitmap = outs.bitmap.data_ptr()
+    def _check_stream(self, what):
         # kernel -> all-gather -> merge are ordered by ONE stream: the collective goes to torch's current stream, so a
         # HIP context must have been created on that very stream (the CPU stand-ins of the tests have no `stream`)
         if self._on_gpu and hasattr(self.pipe, "stream"):
             current = self.torch.cuda.current_stream(self.device).cuda_stream
             if self.pipe.stream is None or int(self.pipe.stream) != int(current):
-                raise ValueError("DrawListExchange.step: the pipeline's stream is not torch's current stream — create it with "
-                                 "InstancePipeline(..., stream=torch.cuda.current_stream(device).cuda_stream) and call step() "
+                raise ValueError(f"DrawListExchange.{what}: the pipeline's stream is not torch's current stream — create it with "
+                                 "InstancePipeline(..., stream=torch.cuda.current_stream(device).cuda_stream) and call it "
                                  "under that stream; the all-gather would otherwise race with the kernels")
+
+    def step(self, frame, outs=None, model=0, visible_bitmap=0, world_aabb=0, kernel_done=None):
+        """One frame on this rank. `outs` (optional) supplies model / bitmap device buffers. `kernel_done`
+        (optional, a torch.cuda.Event) is recorded right behind the shard kernel, in front of the all-gather."""
+        if outs is not None:
+            model = outs.model.data_ptr()
+            visible_bitmap = outs.bitmap.data_ptr()
+        self._check_stream("step")
         base = self._send_full.data_ptr()
         self.pipe.run_device(frame, model=model, visible_bitmap=visible_bitmap, world_aabb=world_aabb,
                              draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4,
-                             async_=True)
+                             async_=True, **({"wire": True} if self.wire else {}))
+        if kernel_done is not None:
+            kernel_done.record()
         self._gather_and_merge()
         self._in_flight += 1
 
     def _gather_and_merge(self):
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        self.pipe.merge_draw_lists(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(),
-                                   self.merged_count.data_ptr(), async_=True, chunk_capacity=self.capacity)
+        merge = self.pipe.merge_wire_lists if self.wire else self.pipe.merge_draw_lists
+        merge(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(), self.merged_count.data_ptr(), async_=True,
+              chunk_capacity=self.capacity)
 
     def complete(self):
         """Block until the frames issued so far are done. If the LAST one overflowed its tightened chunk,
         repeat its all-gather + merge at full capacity (collective: the overflow is visible in the headers
         every rank gathered, so every rank takes this branch together). Returns True if it had to."""
+        self._check_stream("complete")  # a repair issues an all-gather: it must land on the pipeline's stream
         in_flight, self._in_flight = self._in_flight, 0
         try:
             self.pipe.wait()
@@ -109,7 +129,7 @@ class DrawListExchange:
             if in_flight != 1:
                 raise MipError(e.code, "a tightened chunk overflowed with several frames in flight: the overflowing "
                                        "frame's list has been overwritten; call complete() after every frame") from e
-        self.set_capacity(self.n_local)
+        self.set_capacity(self.n_max)
         self._gather_and_merge()
         self.pipe.wait()
         self.retries += 1
@@ -144,9 +164,16 @@ class DrawListExchange:
 class PipelinedExchange:
     """F frames in flight on the sharded path: F contexts, each bound to its own torch stream
     (kernel -> all-gather -> merge stay ordered within a frame), issued round-robin so that
-    frame k+1's kernel runs while frame k's draw lists are still on the wire."""
+    frame k+1's kernel runs while frame k's draw lists are still on the wire.
 
-    def __init__(self, make_pipe, n_local, world, rank, device, frames=2, dist=None, torch=None, group=None):
+    What overlaps is a shard KERNEL with the previous frames' all-gather and merge — never two shard kernels:
+    slot k's kernel waits (stream-side, an event) for the previous slot's kernel. Two spin-waiting launches that
+    are each only partly resident are the shape that deadlocked in round 2 (every resident
+    tile of one waits for a tile that cannot start because the other's waiting tiles hold the CUs, and vice
+    versa); a collective kernel beside a shard kernel is not that shape — its workgroups wait for peers, never
+    for this GPU's shard kernel, so they always drain (tests/fake_ccl/spin_rccl.hip rehearses exactly this)."""
+
+    def __init__(self, make_pipe, n_local, world, rank, device, frames=2, dist=None, torch=None, group=None, wire=True):
         if torch is None:
             import torch
         self.torch = torch
@@ -154,9 +181,19 @@ class PipelinedExchange:
         # on a GPU every frame slot has its own stream; the CPU tests (gloo) run the same rotation on the host
         self.streams = [torch.cuda.Stream(device=device) if self.on_gpu else None for _ in range(frames)]
         self.pipes = [make_pipe(st.cuda_stream if st is not None else 0) for st in self.streams]
-        self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group)
+        self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group, wire=wire)
                           for p in self.pipes]
+        self.kernel_done = [torch.cuda.Event() if self.on_gpu else None for _ in range(frames)]
+        self.last = None  # slot whose shard kernel was issued last
         self.next = 0
+
+    def _under(self, k, fn):
+        """Runs fn under slot k's stream: everything an exchange enqueues (also the repair of an overflowed chunk,
+        whose all-gather goes to torch's CURRENT stream) must be ordered with that slot's kernels and merges."""
+        if self.on_gpu:
+            with self.torch.cuda.stream(self.streams[k]):
+                return fn()
+        return fn()
 
     def step(self, frame, outs_per_frame):
         """Issues one frame on the next slot. A slot is reused every `frames` steps: its previous frame is
@@ -165,19 +202,22 @@ class PipelinedExchange:
         k = self.next
         self.next = (k + 1) % len(self.exchanges)
         ex = self.exchanges[k]
-        if ex.capacity < ex.n_local and ex._in_flight:
-            ex.complete()
-        if self.on_gpu:
-            with self.torch.cuda.stream(self.streams[k]):
-                ex.step(frame, outs_per_frame[k])
-        else:
-            ex.step(frame, outs_per_frame[k])
+
+        def issue():
+            if ex.capacity < ex.n_max and ex._in_flight:
+                ex.complete()
+            if self.on_gpu and self.last is not None and self.last != k:
+                self.streams[k].wait_event(self.kernel_done[self.last])  # shard kernels never overlap each other
+            ex.step(frame, outs_per_frame[k], kernel_done=self.kernel_done[k])
+
+        self._under(k, issue)
+        self.last = k
         return k
 
     def wait(self):
         """Drains every frame slot; a slot whose last frame overflowed its tightened chunk is repaired
         (DrawListExchange.complete). Collective, like step()."""
-        return [ex.complete() for ex in self.exchanges]
+        return [self._under(k, ex.complete) for k, ex in enumerate(self.exchanges)]
 
     def tighten(self, margin=1.0625):
         return [ex.tighten(margin) for ex in self.exchanges]

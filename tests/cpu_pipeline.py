@@ -6,7 +6,49 @@ import ctypes as C
 import numpy as np
 
 import oracle
-from renderer_amd.pipeline import DRAW_CMD_DTYPE, SHARD_HEADER_BYTES
+from renderer_amd.pipeline import DRAW_CMD_DTYPE, SHARD_HEADER_BYTES, wire_body_bytes
+
+WIRE_BLOCK = 256            # MIP_WIRE_BLOCK_COMMANDS
+WIRE_BLOCK_WORDS = 4 + 2 * WIRE_BLOCK
+
+
+def encode_wire(cmds, mesh_of_cmd, far_of_cmd):
+    """The wire form of a 20-byte command list (include/mi_instance_pipeline.h, MIP_OUT_WIRE), restated in numpy:
+    blocks of 256 records {firstInstance, mesh | far << 31}, each behind a 16-byte header whose first word is the
+    firstIndex of the block's first command. Returns the body as uint32 words (whole blocks; unused slots zero)."""
+    n = len(cmds)
+    blocks = (n + WIRE_BLOCK - 1) // WIRE_BLOCK
+    body = np.zeros(blocks * WIRE_BLOCK_WORDS, np.uint32)
+    v = body.reshape(blocks, WIRE_BLOCK_WORDS)
+    if n:
+        v[:, 0] = cmds["firstIndex"][::WIRE_BLOCK]
+        rec = np.zeros((blocks * WIRE_BLOCK, 2), np.uint32)
+        rec[:n, 0] = cmds["firstInstance"]
+        rec[:n, 1] = np.asarray(mesh_of_cmd, np.uint32) | (np.asarray(far_of_cmd, np.uint32) << np.uint32(31))
+        v[:, 4:] = rec.reshape(blocks, 2 * WIRE_BLOCK)
+    return body
+
+
+def decode_wire(body, count, meshes):
+    """Expands `count` wire records against the mesh table: what mip_merge_wire_lists_kernel does for one chunk
+    (without the rebasing over chunks)."""
+    blocks = (count + WIRE_BLOCK - 1) // WIRE_BLOCK
+    v = np.asarray(body[: blocks * WIRE_BLOCK_WORDS], np.uint32).reshape(blocks, WIRE_BLOCK_WORDS)
+    rec = v[:, 4:].reshape(-1, 2)[:count]
+    mesh = rec[:, 1] & np.uint32(0x7FFFFFFF)
+    far = rec[:, 1] >> np.uint32(31)
+    n_lods = meshes["n_lods"][mesh]
+    lens = np.where((far == 1) & (n_lods > 1), meshes["index_len"][mesh, 1], meshes["index_len"][mesh, 0]).astype(np.uint32)
+    out = np.zeros(count, DRAW_CMD_DTYPE)
+    out["indexCount"] = lens
+    out["instanceCount"] = 1
+    out["vertexOffset"] = meshes["vertex_offset"][mesh]
+    out["firstInstance"] = rec[:, 0]
+    for b in range(blocks):
+        sl = slice(b * WIRE_BLOCK, min(count, (b + 1) * WIRE_BLOCK))
+        l = lens[sl].astype(np.uint64)
+        out["firstIndex"][sl] = ((np.cumsum(l) - l + np.uint64(v[b, 0])) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    return out
 
 
 def _view(ptr, nbytes, dtype):
@@ -20,7 +62,7 @@ class OraclePipeline:
         self.n = scene["n"]
 
     def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0, draw_index_total=0,
-                   world_aabb=0, async_=False):
+                   world_aabb=0, async_=False, wire=False):
         s = self.s
         r = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], np.array(frame.planes[:], np.float32),
                        np.array(frame.cam_pos[:], np.float32), first_instance_base=frame.first_instance_base,
@@ -30,7 +72,17 @@ class OraclePipeline:
             _view(model, n * 64, np.float32)[:] = r["model"].reshape(-1)
         if visible_bitmap:
             _view(visible_bitmap, ((n + 31) // 32) * 4, np.uint32)[:] = r["visible_bitmap"]
-        if draw_cmds:
+        if draw_cmds and wire:
+            c = r["draw_count"]
+            inst = (r["draw_cmds"]["firstInstance"] - np.uint32(frame.first_instance_base)).astype(np.int64)
+            cam = np.array(frame.cam_pos[:], np.float32)
+            far = np.array([oracle.pick_lod(2, cam, s["pos"][i]) for i in inst], np.uint32)
+            body = encode_wire(r["draw_cmds"], s["mesh_id"][inst], far)
+            _view(draw_cmds, body.nbytes, np.uint32)[:] = body
+            _view(draw_count, 4, np.uint32)[0] = c
+            if draw_index_total:
+                _view(draw_index_total, 4, np.uint32)[0] = r["draw_index_total"]
+        elif draw_cmds:
             c = r["draw_count"]
             _view(draw_cmds, c * 20, np.uint8)[:] = r["draw_cmds"].view(np.uint8).reshape(-1)
             _view(draw_count, 4, np.uint32)[0] = c
@@ -56,6 +108,25 @@ class OraclePipeline:
                 count = capacity
                 self._overflow = True
             lists.append(_view(chunks_ptr + k * stride + SHARD_HEADER_BYTES, count * 20, np.uint8).view(DRAW_CMD_DTYPE).copy())
+            totals.append(int(h[1]))
+        merged, index_total = oracle.merge_draw_lists(lists, totals)
+        _view(out_cmds_ptr, len(merged) * 20, np.uint8)[:] = merged.view(np.uint8).reshape(-1)
+        oc = _view(out_count_ptr, 8, np.uint32)
+        oc[0] = len(merged)
+        oc[1] = index_total
+
+    def merge_wire_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0):
+        lists, totals = [], []
+        fits = (stride - SHARD_HEADER_BYTES) // (WIRE_BLOCK_WORDS * 4) * WIRE_BLOCK
+        capacity = min(chunk_capacity, fits) if chunk_capacity else fits
+        for k in range(n_chunks):
+            h = _view(chunks_ptr + k * stride, 8, np.uint32)
+            count = int(h[0])
+            if count > capacity:
+                count = capacity
+                self._overflow = True
+            body = _view(chunks_ptr + k * stride + SHARD_HEADER_BYTES, wire_body_bytes(count), np.uint32)
+            lists.append(decode_wire(body, count, self.s["meshes"]))
             totals.append(int(h[1]))
         merged, index_total = oracle.merge_draw_lists(lists, totals)
         _view(out_cmds_ptr, len(merged) * 20, np.uint8)[:] = merged.view(np.uint8).reshape(-1)

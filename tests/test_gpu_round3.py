@@ -1,0 +1,500 @@
+"""Round-3 additions, all through the C ABI on the GPU: the wire form of a shard's draw list (8-byte records
+through the all-gather, expanded by the merge), the sharded frame beside a collective kernel that spin-waits on the
+device, the overflow repair of a pipelined exchange under its own stream, and the hardened device-pointer upload."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import run_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import renderer_amd
+
+    renderer_amd.load_library()  # fails loudly if the HIP library is missing
+    return renderer_amd
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _far_bits(oracle_mod, s, cmds, base, cam):
+    inst = (cmds["firstInstance"] - np.uint32(base)).astype(np.int64)
+    d = np.asarray(cam, np.float32)[None, :] - s["pos"][inst]
+    # pick_lod's distance test (helpers.rs:4) vectorised: sqrt_rn(q) > 10 <=> q > nextafter(100)
+    q = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + (d[:, 2] * d[:, 2]).astype(np.float32)
+    far = (q.astype(np.float32) > np.float32(100.00000762939453125)).astype(np.uint32)
+    for k in range(0, len(inst), max(1, len(inst) // 64)):  # spot-check against the oracle's scalar pick_lod
+        assert far[k] == oracle_mod.pick_lod(2, cam, s["pos"][inst[k]])
+    return inst, far
+
+
+@pytest.mark.parametrize("n", [1, 255, 300, 1024, 4_097, 100_000, 1_000_003])
+def test_wire_list_is_the_command_list(ra, oracle_mod, n):
+    """MIP_OUT_WIRE: the kernel's wire bytes are the numpy restatement's (tests/cpu_pipeline.py encode_wire) of the
+    oracle's command list, and expanding them against the mesh table gives the oracle's 20-byte commands back."""
+    import torch
+
+    from cpu_pipeline import decode_wire, encode_wire
+    from renderer_amd.pipeline import make_frame, wire_body_bytes
+
+    s = ra.scene.make_scene(3, n=n)
+    if n == 300:
+        s = ra.scene.make_scene(3, n=n, all_visible=True)  # 300 commands: crosses a block boundary at a non-tile position
+    dev = torch.device("cuda", 0)
+    base, index_base = 1000, 77
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",), first_instance_base=base, first_index_base=index_base)
+    cmds = want["draw_cmds"]
+    with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        body = torch.full((wire_body_bytes(n) // 4 + 4,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=base, first_index_base=index_base)
+        for order in (None, "1", "3"):
+            if order:
+                os.environ["MIP_TUNE_ORDER"] = order
+            try:
+                with ra.InstancePipeline(max_instances=n, max_meshes=64) as q:
+                    q.set_mesh_table(s["meshes"])
+                    q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+                    body.fill_(0x5A5A5A5A)
+                    torch.cuda.synchronize()
+                    q.run_device(frame, draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire=True)
+            finally:
+                os.environ.pop("MIP_TUNE_ORDER", None)
+            count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+            assert count == want["draw_count"] and total == want["draw_index_total"]
+            got = body.cpu().numpy().view(np.uint32)
+            inst, far = _far_bits(oracle_mod, s, cmds, base, s["cam_pos"])
+            ref = encode_wire(cmds, s["mesh_id"][inst], far)
+            blocks = (count + 255) // 256
+            g = got[: blocks * 516].reshape(blocks, 516)
+            r = ref.reshape(blocks, 516)
+            assert np.array_equal(g[:, 0], r[:, 0]), f"order {order}: block headers"
+            # records of the live commands (slots past the count of the last block are never written)
+            live = np.zeros((blocks, 256), bool)
+            live.reshape(-1)[:count] = True
+            assert np.array_equal(g[:, 4:].reshape(blocks, 256, 2)[live], r[:, 4:].reshape(blocks, 256, 2)[live]), f"order {order}: records"
+            assert np.all(got[blocks * 516:] == 0x5A5A5A5A), "nothing is written past the last block"
+            assert decode_wire(got, count, s["meshes"]).tobytes() == cmds.tobytes()
+        with pytest.raises(ra.MipError):  # the wire form cannot carry the per-triangle stage's counts
+            p.run_device(frame, model=body.data_ptr(), draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), wire=True,
+                         culled_index_buffer=body.data_ptr(), culled_index_capacity=4)
+
+
+@pytest.mark.parametrize("n_global,world", [(10, 3), (70_001, 3), (1_000_000, 8)])
+def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
+    """Shards of one scene run into wire chunks and into 20-byte chunks laid out as an all-gather would; both merges
+    give the unsharded oracle's list, byte for byte — also with a tightened capacity, whose overflow is reported."""
+    import torch
+
+    from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
+    from renderer_amd.sharded import chunk_stride_bytes, shard_range
+
+    dev = torch.device("cuda", 0)
+    full = ra.scene.make_scene(3, n=n_global)
+    want = run_oracle(oracle_mod, full, threads=8, want=("draw_cmds",))
+    per = (n_global + world - 1) // world
+    strides = {w: chunk_stride_bytes(per, wire=w) for w in (True, False)}
+    recv = {w: torch.zeros(world * strides[w] // 4, dtype=torch.int32, device=dev) for w in (True, False)}
+    counts = []
+    for r in range(world):
+        lo, hi = shard_range(n_global, world, r)
+        sh = ra.scene.make_scene(3, n=hi - lo, first=lo)
+        with ra.InstancePipeline(max_instances=max(hi - lo, 1), max_meshes=64) as p:
+            p.set_mesh_table(sh["meshes"])
+            p.set_instances(sh["pos"], sh["rot"], sh["scale"], sh["mesh_id"])
+            frame = make_frame(full["planes"], full["cam_pos"], first_instance_base=lo)
+            for w in (True, False):
+                base = recv[w].data_ptr() + r * strides[w]
+                p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire=w)
+            counts.append(int(recv[True][r * strides[True] // 4].item()))
+    assert sum(counts) == want["draw_count"]
+    merged = torch.zeros((world * per + 1, 5), dtype=torch.int32, device=dev)
+    scal = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with ra.InstancePipeline(max_instances=1, max_meshes=64) as p:
+        p.set_mesh_table(full["meshes"])
+        for w in (True, False):
+            merged.fill_(-1)
+            torch.cuda.synchronize()
+            merge = p.merge_wire_lists if w else p.merge_draw_lists
+            merge(recv[w].data_ptr(), world, strides[w], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
+            count, index_total = (int(x) & 0xFFFFFFFF for x in scal.cpu().tolist())
+            assert count == want["draw_count"] and index_total == want["draw_index_total"], (w, count)
+            assert merged[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), f"wire={w}"
+            assert bool((merged[count:] == -1).all()), "nothing is written past the merged list"
+        if max(counts) > 256:
+            # a tightened slice: whole blocks only; the largest shard no longer fits -> cut there and reported
+            cap = (max(counts) - 1) // 256 * 256
+            tight = chunk_stride_bytes(cap, wire=True)
+            small = torch.zeros(world * tight // 4, dtype=torch.int32, device=dev)
+            for r in range(world):
+                small[r * tight // 4:(r + 1) * tight // 4] = recv[True][r * strides[True] // 4: r * strides[True] // 4 + tight // 4]
+            torch.cuda.synchronize()
+            with pytest.raises(ra.MipError) as e:
+                p.merge_wire_lists(small.data_ptr(), world, tight, merged.data_ptr(), scal.data_ptr(), chunk_capacity=cap)
+            assert e.value.code == -4
+            assert int(scal[0].item()) == sum(min(c, cap) for c in counts)
+        # a record that names a mesh outside the table is never followed: reported, expanded as mesh 0
+        if counts[0] > 0:
+            bad = recv[True].clone()
+            bad[SHARD_HEADER_BYTES // 4 + 4 + 1] = 64  # first record's second word: mesh 64 of a 64-entry table
+            torch.cuda.synchronize()
+            with pytest.raises(ra.MipError) as e:
+                p.merge_wire_lists(bad.data_ptr(), world, strides[True], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
+            assert e.value.code == -5 and "mesh" in str(e.value)
+        with pytest.raises(ra.MipError):  # a stride that cannot hold the capacity
+            p.merge_wire_lists(recv[True].data_ptr(), world, 256, merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
+
+
+_SPIN_RANK = r'''
+import os, sys
+root, rank, world, n_global, id_path, out_path, frames = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6], int(sys.argv[7])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import time
+import numpy as np, torch
+import renderer_amd, oracle
+from renderer_amd import scene
+from renderer_amd.pipeline import make_frame
+from renderer_amd.sharded import shard_range
+
+full = scene.make_scene(3, n=n_global)
+lo, hi = shard_range(n_global, world, rank)
+s = scene.make_scene(3, n=hi - lo, first=lo)
+if rank == 0:
+    uid = renderer_amd.InstancePipeline.comm_unique_id()
+    open(id_path + ".tmp", "wb").write(uid); os.rename(id_path + ".tmp", id_path)
+else:
+    t0 = time.time()
+    while not os.path.exists(id_path):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    uid = open(id_path, "rb").read()
+dev = torch.device("cuda", 0)
+want = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], full["planes"], full["cam_pos"], threads=4, want=("draw_cmds",))
+per = (n_global + world - 1) // world
+timeouts = 0
+with renderer_amd.InstancePipeline(max_instances=hi - lo, max_meshes=64) as p:
+    p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+    p.comm_init(uid, rank, world)
+    merged = torch.zeros((world * per, 5), dtype=torch.int32, device=dev)
+    count = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    frame = make_frame(full["planes"], full["cam_pos"], first_instance_base=lo)
+    def check(what):
+        total, index_total = (int(x) & 0xFFFFFFFF for x in count.cpu().tolist())
+        assert total == want["draw_count"] and index_total == want["draw_index_total"], (what, total, want["draw_count"])
+        assert merged[:total].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
+    # `frames` asynchronous frames back to back: while this rank's collective kernel of frame k spin-waits on the
+    # device for its peers, the peers' shard kernels of frame k (and this rank's of k + 1, queued behind) need the
+    # same GPU. EVERY rank issues exactly the same sequence of collectives whatever happens locally: a rank whose
+    # frame timed out reports it (the context falls back to ordered tiles by itself) and goes on.
+    for k in range(frames):
+        p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), async_=True)
+        if k % 8 == 7:
+            try:
+                p.wait()
+            except renderer_amd.MipError as e:
+                assert e.code == -7, e
+                timeouts += 1
+    try:
+        p.wait()
+    except renderer_amd.MipError as e:
+        assert e.code == -7, e
+        timeouts += 1
+    # whatever happened above, the frames after it are right on every rank (no timeout: straight away; after a
+    # timeout: in ordered-tiles mode). Two settle frames let a peer that timed out in the last batch catch up.
+    ok = 0
+    for k in range(4):
+        try:
+            p.run_sharded(frame, merged.data_ptr(), count.data_ptr())
+            if k >= 2:
+                check(f"settled frame {k}")
+                ok += 1
+        except renderer_amd.MipError as e:
+            assert e.code == -7, e
+            timeouts += 1
+    assert ok >= 1
+    sent = p.timings()["sharded_bytes_sent"]
+    p.comm_destroy()
+open(out_path, "w").write(f"ok timeouts={timeouts} sent={sent}")
+'''
+
+
+def _build_double(tmp_path, name):
+    so = str(tmp_path / f"lib{name}.so")
+    src = os.path.join(ROOT, "tests", "fake_ccl", name + (".hip" if name == "spin_rccl" else ".cpp"))
+    if name == "spin_rccl":
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", so, "-lrt"])
+    else:
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", so,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    return so
+
+
+@pytest.mark.parametrize("world,workgroups", [(2, 64), (3, 512)])
+def test_sharded_frames_beside_a_collective_that_spin_waits_on_the_device(ra, tmp_path, world, workgroups):
+    """The co-tenant shape of DESIGN.md section 4: the collective is a KERNEL of persistent workgroups that spin-wait on
+    the device for the peers (tests/fake_ccl/spin_rccl.hip), enqueued asynchronously like RCCL's, and the ranks —
+    one process each — share this box's one GPU, so shard kernels of one rank run beside spinning collective
+    workgroups of another. Must end with every rank holding the unsharded oracle's list: without a timeout, or —
+    if the dispatch-order assumption breaks — with MIP_ERR_TIMEOUT reported and the frames after it right (the
+    context switches itself to ordered tiles). Never a hang, never a silent wrong list."""
+    fake = _build_double(tmp_path, "spin_rccl")
+    env = dict(os.environ, MIP_COMM_LIBRARY=fake, SPIN_CCL_WORKGROUPS=str(workgroups))
+    id_path = str(tmp_path / "uid")
+    n_global = 600_001
+    procs = [subprocess.Popen([sys.executable, "-c", _SPIN_RANK, ROOT, str(r), str(world), str(n_global), id_path, str(tmp_path / f"ok{r}"), "48"],
+                              env=env, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = [p.communicate(timeout=420)[1] for p in procs]
+    notes = []
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and os.path.exists(tmp_path / f"ok{r}"), f"rank {r}:\n{errs[r][-3000:]}"
+        notes.append(open(tmp_path / f"ok{r}").read())
+    print("spin ccl:", notes)
+    # the chunk a rank sent is the wire form: 8.06 B per command (+ header), 40 % of the 20-byte form
+    per = (n_global + world - 1) // world
+    sent = int(notes[0].split("sent=")[1])
+    assert sent == (32 + (per + 255) // 256 * 2064 + 255) // 256 * 256 < 0.41 * (32 + per * 20)
+
+
+def test_pipelined_exchange_repairs_an_overflow_under_its_own_stream(ra, oracle_mod):
+    """the repair of an overflowed tightened chunk (all-gather + merge again at full capacity) must run on
+    the slot's stream — with two frames in flight the current stream is not it. Camera A, tighten, then camera B
+    (sees more): every slot's merged list must be B's, complete."""
+    import torch
+    import torch.distributed as dist
+
+    from renderer_amd.sharded import PipelinedExchange, make_shard_frame
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        s = ra.scene.make_scene(3, n=700_000)
+        cam_b = np.array([0.0, 1.0, -40.0], np.float32)
+        planes_b = oracle_mod.project_camera(cam_b, (0.0, 0.0, 0.0, 1.0))
+        want_a = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+        want_b = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], planes_b, cam_b, threads=8, want=("draw_cmds",))
+        assert want_b["draw_count"] > 1.2 * want_a["draw_count"]
+
+        def make_pipe(stream_handle):
+            q = ra.InstancePipeline(max_instances=s["n"], max_meshes=64, stream=stream_handle)
+            q.set_mesh_table(s["meshes"])
+            q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            return q
+
+        for wire in (True, False):
+            px = PipelinedExchange(make_pipe, s["n"], 1, 0, dev, frames=2, wire=wire)
+            frame_a = make_shard_frame(s["planes"], s["cam_pos"], s["n"], 1, 0)
+            frame_b = make_shard_frame(planes_b, cam_b, s["n"], 1, 0)
+            torch.cuda.synchronize()
+            for _ in range(4):
+                px.step(frame_a, [None, None])
+            assert px.wait() == [False, False]
+            caps = px.tighten()
+            assert max(caps) < s["n"]
+            for f in (frame_a, frame_b, frame_b, frame_a, frame_b, frame_b):  # overflows are repaired inside step() and wait()
+                px.step(f, [None, None])
+            px.wait()
+            assert sum(ex.retries for ex in px.exchanges) >= 1
+            for ex in px.exchanges:
+                cmds, total, index_total = px._under(px.exchanges.index(ex), ex.merged_draw_list)
+                assert total == want_b["draw_count"] and index_total == want_b["draw_index_total"], (wire, total)
+                assert cmds.tobytes() == want_b["draw_cmds"].tobytes(), f"wire={wire}"
+            # complete() refuses to run a repair on a foreign stream instead of racing
+            with pytest.raises(ValueError):
+                px.exchanges[0].complete()
+            px.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_upload_rejects_mesh_ids_outside_the_table(ra):
+    """mip_set_instances_device used to trust mesh ids (an id >= m became an out-of-bounds gather in the frame kernel);
+    the upload-time census now counts them and the call fails like mip_set_instances does."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    s = ra.scene.make_scene(3, n=10_000)
+    cols = [torch.from_numpy(np.ascontiguousarray(s[k])).to(dev) for k in ("pos", "rot", "scale")]
+    good = torch.from_numpy(s["mesh_id"].astype(np.int32)).to(dev)
+    bad = good.clone()
+    bad[9_999] = 64
+    torch.cuda.synchronize()
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        with pytest.raises(ra.MipError) as e:
+            p.set_instances_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), bad.data_ptr(), s["n"])
+        assert e.value.code == -1 and "mesh id" in str(e.value)
+        with pytest.raises(ra.MipError) as e:  # nothing became resident
+            p.run_host(s["planes"], s["cam_pos"])
+        assert e.value.code == -6
+        p.set_instances_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), good.data_ptr(), s["n"])
+        got = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))
+        assert got["draw_count"] > 0
+        # a smaller table afterwards: the resident ids are checked against it at the next upload of either
+        with pytest.raises(ra.MipError) as e:
+            p.set_mesh_table(s["meshes"][:10])
+        assert e.value.code == -1
+
+
+# ---- row f-2, the semaphore half -------------------------------------------------------------------------------
+# A Vulkan timeline semaphore exported with vkGetSemaphoreFdKHR(OPAQUE_FD) is, on amdgpu, the fd of a DRM sync object.
+# There is no Vulkan device on the build boxes, but the kernel object itself can be made through the render node's
+# DRM_IOCTL_SYNCOBJ_* ioctls — standing in for the renderer's export, as the dma-buf of another process does for memory.
+
+def _drm_iowr(nr, size):
+    return (3 << 30) | (size << 16) | (ord("d") << 8) | nr
+
+
+class _SyncObj:
+    """A DRM timeline sync object on the first render node that allows it, exportable as an fd."""
+
+    def __init__(self):
+        import fcntl
+        import glob
+        import struct
+
+        self.fcntl, self.struct = fcntl, struct
+        self.fd, self.handle, self.why = -1, 0, "no /dev/dri/renderD* node"
+        for node in sorted(glob.glob("/dev/dri/renderD*")):
+            try:
+                fd = os.open(node, os.O_RDWR | os.O_CLOEXEC)
+            except OSError as e:
+                self.why = f"{node}: {e}"
+                continue
+            try:
+                buf = bytearray(struct.pack("II", 0, 0))
+                fcntl.ioctl(fd, _drm_iowr(0xBF, 8), buf)  # DRM_IOCTL_SYNCOBJ_CREATE
+                self.fd, self.handle = fd, struct.unpack("II", buf)[0]
+                return
+            except OSError as e:
+                self.why = f"{node}: SYNCOBJ_CREATE: {e}"
+                os.close(fd)
+
+    def export_fd(self):
+        buf = bytearray(self.struct.pack("IIiI", self.handle, 0, -1, 0))
+        self.fcntl.ioctl(self.fd, _drm_iowr(0xC1, 16), buf)  # DRM_IOCTL_SYNCOBJ_HANDLE_TO_FD
+        return self.struct.unpack("IIiI", buf)[2]
+
+    def query(self):
+        import ctypes as C
+
+        h, p = (C.c_uint32 * 1)(self.handle), (C.c_uint64 * 1)(0)
+        buf = bytearray(self.struct.pack("QQII", C.addressof(h), C.addressof(p), 1, 0))
+        self.fcntl.ioctl(self.fd, _drm_iowr(0xCB, 24), buf)  # DRM_IOCTL_SYNCOBJ_QUERY
+        return int(p[0])
+
+    def signal(self, value):
+        import ctypes as C
+
+        h, p = (C.c_uint32 * 1)(self.handle), (C.c_uint64 * 1)(value)
+        buf = bytearray(self.struct.pack("QQII", C.addressof(h), C.addressof(p), 1, 0))
+        self.fcntl.ioctl(self.fd, _drm_iowr(0xCD, 24), buf)  # DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL
+
+    def close(self):
+        if self.fd >= 0:
+            os.close(self.fd)
+
+
+def test_external_semaphore_entry_points(ra, oracle_mod):
+    """mip_import_external_semaphore_fd / mip_wait_external / mip_signal_external / mip_release_external_semaphore: the
+    error paths always; and, when the runtime accepts the handle, the whole hand-over against a DRM timeline sync
+    object (what vkGetSemaphoreFdKHR exports on amdgpu): a frame that waits for value 1, runs, and signals value 2."""
+    import time
+
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    dev = torch.device("cuda", 0)
+    s = ra.scene.make_scene(3, n=50_000)
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+    notes = []
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p, ra.InstancePipeline(max_instances=1, max_meshes=1) as other:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        # -- error paths --
+        with pytest.raises(ra.MipError) as e:
+            p.import_external_semaphore_fd(-1)
+        assert e.value.code == -1
+        with pytest.raises(ra.MipError) as e:
+            p.import_external_semaphore_fd(0, timeline=7)  # not a kind
+        assert e.value.code == -1
+        r, w = os.pipe()
+        try:
+            with pytest.raises(ra.MipError) as e:  # an fd that is no semaphore: refused by the runtime, reported, nothing leaks
+                p.import_external_semaphore_fd(r)
+            assert e.value.code == -5 and "hipImportExternalSemaphore" in str(e.value)
+            notes.append(f"pipe fd as TimelineSemaphoreFd -> {e.value}")
+        finally:
+            os.close(r)
+            os.close(w)
+        bogus = 0x1234
+        for call in (lambda: p.wait_external(bogus, 1), lambda: p.signal_external(bogus, 1), lambda: p.release_external_semaphore(bogus)):
+            with pytest.raises(ra.MipError) as e:
+                call()
+            assert e.value.code == -1
+        # -- the hand-over against a real kernel sync object --
+        so = _SyncObj()
+        if so.fd < 0:
+            notes.append(f"no DRM sync object available ({so.why}): hand-over not exercised")
+        else:
+            try:
+                for timeline in (True, False):
+                    fd = so.export_fd()
+                    try:
+                        sem = p.import_external_semaphore_fd(fd, timeline=timeline)
+                    except ra.MipError as e:
+                        assert e.code == -5
+                        notes.append(f"DRM syncobj fd as {'Timeline' if timeline else 'Opaque'}Fd -> {e}")
+                        os.close(fd)
+                        continue
+                    notes.append(f"DRM syncobj fd as {'Timeline' if timeline else 'Opaque'}Fd -> imported")
+                    with pytest.raises(ra.MipError):  # a handle belongs to the context that imported it
+                        other.release_external_semaphore(sem)
+                    if timeline:
+                        cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+                        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+                        torch.cuda.synchronize()
+                        frame = make_frame(s["planes"], s["cam_pos"])
+                        p.wait_external(sem, 1)                      # the frame may not start before the "renderer" reaches 1
+                        p.run_device(frame, draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), async_=True)
+                        p.signal_external(sem, 2)                    # reached when the frame's kernel has finished
+                        time.sleep(0.2)
+                        assert so.query() < 2, "the frame ran before the semaphore it waits for was signalled"
+                        so.signal(1)                                 # the renderer's submit completes
+                        t0 = time.time()
+                        while so.query() < 2 and time.time() - t0 < 10:
+                            time.sleep(0.001)
+                        assert so.query() == 2, "the signal behind the frame never arrived"
+                        # value 2 means the frame's outputs are complete — read without any mip_wait
+                        count = int(scal[0].item())
+                        assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+                        p.wait()
+                        notes.append("timeline hand-over: wait(1) -> frame -> signal(2) observed through the DRM sync object")
+                    p.release_external_semaphore(sem)
+                    with pytest.raises(ra.MipError):
+                        p.release_external_semaphore(sem)            # released once
+            finally:
+                so.close()
+    print("external semaphores:", notes)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "external_semaphore_notes.txt"), "w").write("\n".join(notes) + "\n")

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, init_file, n_global, tighten, out_dir):
+def _worker(rank, world, init_file, n_global, tighten, out_dir, wire=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import oracle
@@ -31,14 +31,15 @@ def _worker(rank, world, init_file, n_global, tighten, out_dir):
         assert np.array_equal(shard["pos"], full["pos"][lo:hi])
         pipe = OraclePipeline(shard)
         n_local = hi - lo
-        ex = DrawListExchange(pipe, n_local, world, rank, torch.device("cpu"), dist=dist, torch=torch)
+        ex = DrawListExchange(pipe, n_local, world, rank, torch.device("cpu"), dist=dist, torch=torch, wire=wire)
+        assert ex.wire == wire
         frame = make_shard_frame(full["planes"], full["cam_pos"], n_global, world, rank)
         bitmap = torch.zeros((n_local + 31) // 32 + 1, dtype=torch.int32)
         model = torch.zeros((max(n_local, 1), 16), dtype=torch.float32)
         ex.step(frame, model=model.data_ptr(), visible_bitmap=bitmap.data_ptr())
         if tighten:
             cap = ex.tighten()
-            assert cap <= max(n_local, 256)
+            assert cap <= max(ex.n_max, 256)
             ex.step(frame, model=model.data_ptr(), visible_bitmap=bitmap.data_ptr())
         cmds, total, index_total = ex.merged_draw_list()
         want = oracle.run(full["pos"], full["rot"], full["scale"], full["mesh_id"], full["meshes"], full["planes"],
@@ -56,11 +57,14 @@ def _worker(rank, world, init_file, n_global, tighten, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_global,tighten", [(2, 20_000, False), (2, 4_097, True), (3, 1_000, True), (2, 1, False)])
-def test_sharded_exchange_matches_unsharded_oracle(world, n_global, tighten):
+@pytest.mark.parametrize("world,n_global,tighten,wire", [(2, 20_000, False, True), (2, 4_097, True, True), (3, 1_000, True, True),
+                                                         (2, 1, False, True), (2, 4_097, True, False), (3, 1_000, False, False)])
+def test_sharded_exchange_matches_unsharded_oracle(world, n_global, tighten, wire):
+    """wire=True: the lists travel as 8-byte records (MIP_OUT_WIRE) and the merge expands them; wire=False: as
+    20-byte commands (round 2). The merged list is the unsharded oracle's either way."""
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
-        mp.spawn(_worker, args=(world, init_file, n_global, tighten, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, init_file, n_global, tighten, d, wire), nprocs=world, join=True)
         for r in range(world):
             assert os.path.exists(os.path.join(d, f"ok{r}"))
 
@@ -75,6 +79,31 @@ def test_shard_ranges_cover_everything():
             for (a, b), (c, e) in zip(spans, spans[1:]):
                 assert b == c and a <= b and c <= e
     assert chunk_stride_bytes(0) == 256 and chunk_stride_bytes(12) % 256 == 0
+    # the wire form: whole blocks of 256 records (2064 B) behind the 32-byte header; ~40 % of the 20-byte form
+    assert chunk_stride_bytes(0, wire=True) == 256 and chunk_stride_bytes(1, wire=True) == 2304
+    assert chunk_stride_bytes(256, wire=True) == 2304 and chunk_stride_bytes(257, wire=True) == 4352
+    assert chunk_stride_bytes(336_000, wire=True) / chunk_stride_bytes(336_000) < 0.41
+
+
+def test_wire_form_round_trips_through_the_numpy_restatement():
+    """encode_wire / decode_wire (tests/cpu_pipeline.py) are the CPU statement of the wire form the kernels speak."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle
+    from cpu_pipeline import WIRE_BLOCK_WORDS, decode_wire, encode_wire
+    from renderer_amd import scene
+
+    for n in (0, 1, 255, 256, 257, 3000):
+        s = scene.make_scene(3, n=max(n, 1))
+        r = oracle.run(s["pos"][:n], s["rot"][:n], s["scale"][:n], s["mesh_id"][:n], s["meshes"], s["planes"], s["cam_pos"],
+                       first_instance_base=77, first_index_base=12345)
+        cmds = r["draw_cmds"]
+        inst = (cmds["firstInstance"] - np.uint32(77)).astype(np.int64)
+        far = np.array([oracle.pick_lod(2, s["cam_pos"], s["pos"][i]) for i in inst], np.uint32)
+        body = encode_wire(cmds, s["mesh_id"][inst], far)
+        assert body.size == (len(cmds) + 255) // 256 * WIRE_BLOCK_WORDS
+        back = decode_wire(body, len(cmds), s["meshes"])
+        assert back.tobytes() == cmds.tobytes(), n
 
 
 def _camera_b():
@@ -124,7 +153,7 @@ def _worker_overflow(rank, world, init_file, n_global, out_dir):
         assert ex.retries == 0
         ex.step(frame_b)                      # the camera moved between tighten() and this frame
         check(ex, want_b, "B, overflow repaired")
-        assert ex.retries == 1 and ex.capacity == n_local
+        assert ex.retries == 1 and ex.capacity == ex.n_max
         ex.step(frame_a)
         check(ex, want_a, "A again")
         assert ex.retries == 1
