@@ -227,8 +227,9 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out);
 void mip_destroy(MipContext* ctx);
 
 /* Copy the mesh table to the device (caller keeps its memory). m <= max_meshes.
- * Bounds must be finite and n_lods in 1..MIP_MAX_LODS. A table smaller than the one it replaces is refused
- * (MIP_ERR_INVALID_ARGUMENT, nothing changes) while a resident instance names a mesh outside it. */
+ * Bounds must be finite and n_lods in 1..MIP_MAX_LODS. If the table is smaller than the one it replaces and a
+ * resident instance names a mesh outside it, the instances stop being resident (upload the new scene's
+ * next; a frame before that fails with MIP_ERR_NOT_READY): the kernels never gather outside the table. */
 int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m);
 
 /* Upload the instance columns: SoA, tightly packed, draw_index = array index
@@ -450,13 +451,21 @@ int32_t mip_release_external(MipContext* ctx, void* device_ptr);
  *
  * and the graphics submit lists sem_cull/value as a wait semaphore: no host wait per frame.
  * kind: MIP_SEMAPHORE_TIMELINE (what the reference uses) or MIP_SEMAPHORE_BINARY (`value` ignored).
- * As with memory, a successfully imported fd belongs to the driver. Errors: MIP_ERR_INVALID_ARGUMENT for
- * a bad fd / kind / a handle this context did not import; MIP_ERR_DEVICE with the runtime's message when
- * HIP refuses the handle. */
+ * As with memory, a successfully imported fd belongs to the library. Two implementations sit behind the
+ * handle: the HIP runtime's (waits and signals execute on the device) when it accepts the handle type, and
+ * otherwise — ROCm 7.2 on Linux refuses both: TimelineSemaphoreFd "invalid argument", OpaqueFd "operation
+ * not supported" — the kernel object itself: on amdgpu the exported fd IS a DRM sync object, which the
+ * library imports on a render node (DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE) and waits for / signals from host
+ * functions enqueued on the frame's stream (hipLaunchHostFunc: stream-ordered, no wait on the caller's
+ * thread; a wait is bounded at 10 s and then reported by mip_wait as MIP_ERR_TIMEOUT).
+ * mip_external_semaphore_on_device tells which one a handle got (1 = HIP runtime, 0 = host functions).
+ * Errors: MIP_ERR_INVALID_ARGUMENT for a bad fd / kind / a handle this context did not import;
+ * MIP_ERR_DEVICE with the runtime's message when neither path accepts the fd. */
 #define MIP_SEMAPHORE_BINARY 0u
 #define MIP_SEMAPHORE_TIMELINE 1u
 typedef struct MipExternalSemaphore MipExternalSemaphore; /* opaque */
 int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t kind, MipExternalSemaphore** out_semaphore);
+int32_t mip_external_semaphore_on_device(MipContext* ctx, MipExternalSemaphore* semaphore);
 int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value);
 int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value);
 /* After mip_wait; mip_destroy releases the rest. */

@@ -137,6 +137,8 @@ extern "C" {
     pub fn mip_release_external(ctx: *mut MipContext, device_ptr: *mut c_void) -> i32;
     /// Row f-2, the semaphore half: a timeline semaphore exported with vkGetSemaphoreFdKHR (renderer.rs:3757-3861).
     pub fn mip_import_external_semaphore_fd(ctx: *mut MipContext, fd: i32, kind: u32, out_semaphore: *mut *mut MipExternalSemaphore) -> i32;
+    /// 1: the HIP runtime imported it (device-side waits); 0: the DRM sync object path (host functions on the stream).
+    pub fn mip_external_semaphore_on_device(ctx: *mut MipContext, semaphore: *mut MipExternalSemaphore) -> i32;
     /// The next frame's stream waits on the device until the semaphore reaches `value`.
     pub fn mip_wait_external(ctx: *mut MipContext, semaphore: *mut MipExternalSemaphore, value: u64) -> i32;
     /// Signals `value` behind the frame issued last.

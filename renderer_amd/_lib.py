@@ -34,7 +34,7 @@ MIP_SEMAPHORE_TIMELINE = 1
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_merge_wire_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_import_external_semaphore_fd", "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_merge_wire_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_import_external_semaphore_fd", "mip_external_semaphore_on_device", "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -189,6 +189,8 @@ def load_library():
     lib.mip_release_external.restype = C.c_int32
     lib.mip_import_external_semaphore_fd.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(vp)]
     lib.mip_import_external_semaphore_fd.restype = C.c_int32
+    lib.mip_external_semaphore_on_device.argtypes = [vp, vp]
+    lib.mip_external_semaphore_on_device.restype = C.c_int32
     lib.mip_wait_external.argtypes = [vp, vp, C.c_uint64]
     lib.mip_wait_external.restype = C.c_int32
     lib.mip_signal_external.argtypes = [vp, vp, C.c_uint64]

@@ -140,7 +140,8 @@ constexpr uint32_t kErrChunkOverflow = 2u;   // word 1: a gathered shard list is
 constexpr uint32_t kErrIndexOverflow = 4u;   // word 2: culled_index_buffer too small
 constexpr uint32_t kErrWireRecord = 8u;      // word 3: a wire record names a mesh outside the table
 constexpr uint32_t kErrPartsTimeout = 16u;   // word 4: a bounded wait of the triangle parts kernel expired
-constexpr uint32_t kErrWords = 5;
+constexpr uint32_t kErrSemaphore = 32u;      // word 5: written by the HOST (a stream-ordered wait on an external semaphore expired)
+constexpr uint32_t kErrWords = 6;
 __device__ __forceinline__ void raise_error(uint32_t* error_flag, uint32_t bit) {
   __hip_atomic_store(error_flag + (31 - __builtin_clz(bit)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -580,7 +581,8 @@ struct CensusArgs {
                   // [1] += number of instances whose mesh id is outside the table (the frame kernel gathers
                   //         meshes[mesh_id] unchecked: such an upload is refused, as mip_set_instances refuses it on the host)
 };
-__global__ __launch_bounds__(256) void mip_count_nonfinite_kernel(const CensusArgs a) {
+// (static: this header is included by two translation units, mip_api.hip and triangle_tu.hip)
+static __global__ __launch_bounds__(256) __attribute__((unused)) void mip_count_nonfinite_kernel(const CensusArgs a) {
   uint32_t bad = 0, bad_id = 0;
   for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.count; k += gridDim.x * 256u) {
     const size_t i = (size_t)a.first + k;

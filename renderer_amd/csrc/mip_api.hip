@@ -9,6 +9,11 @@
 #include <rccl/rccl.h>  // types only: the library is opened with dlopen, never linked
 
 #include <dlfcn.h>
+#include <drm/drm.h>  // DRM sync objects: what an exported Vulkan semaphore fd is on amdgpu (kernel uapi, no libdrm)
+#include <fcntl.h>
+#include <sys/ioctl.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -148,8 +153,13 @@ struct MipContext {
   struct External { hipExternalMemory_t mem; void* ptr; };
   std::vector<External> externals;
   // imported external semaphores (mip_import_external_semaphore_fd); the handle given out is the entry's address
-  struct ExternalSemaphore { hipExternalSemaphore_t sem; uint32_t kind; };
+  // Two implementations behind one handle: the HIP runtime's own (hipImportExternalSemaphore: waits and signals
+  // execute on the device), or — when the runtime refuses the handle type, as ROCm 7.2 on Linux does — the kernel
+  // object itself: the fd of an exported Vulkan semaphore is a DRM sync object on amdgpu, imported on a render node
+  // and waited for / signalled by host functions enqueued on the frame's stream (hipLaunchHostFunc).
+  struct ExternalSemaphore { hipExternalSemaphore_t sem; uint32_t kind; uint32_t drm_handle; };
   std::vector<ExternalSemaphore*> semaphores;
+  int drm_fd = -1;  // render node, opened on first use
   uint32_t last_slot = 0;  // slot of the frame issued last (mip_signal_external goes behind it)
   char err[512] = {0};
 #ifdef MIP_DEBUG_STAMPS
@@ -239,6 +249,8 @@ int32_t check_device_error(MipContext* ctx) {
   }
   if (e & mip::kErrIndexOverflow)
     return fail(ctx, MIP_ERR_CAPACITY, "culled_index_buffer too small for a command's index range; its triangles were dropped");
+  if (e & mip::kErrSemaphore)
+    return fail(ctx, MIP_ERR_TIMEOUT, "a wait for (or signal of) an external semaphore failed or expired after 10 s; the frame behind it ran anyway");
   if (e & mip::kErrWireRecord)
     return fail(ctx, MIP_ERR_DEVICE, "a wire record names a mesh outside this context's mesh table (corrupt chunk, or the ranks hold different tables)");
   return repair_rc;
@@ -467,10 +479,17 @@ void free_all(MipContext* ctx) {
   for (auto& e : ctx->externals) (void)hipDestroyExternalMemory(e.mem);  // unmaps the buffer as well
   ctx->externals.clear();
   for (auto* e : ctx->semaphores) {
-    (void)hipDestroyExternalSemaphore(e->sem);
+    if (e->sem) (void)hipDestroyExternalSemaphore(e->sem);
+    if (e->drm_handle && ctx->drm_fd >= 0) {
+      drm_syncobj_destroy d{};
+      d.handle = e->drm_handle;
+      (void)ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_DESTROY, &d);
+    }
     delete e;
   }
   ctx->semaphores.clear();
+  if (ctx->drm_fd >= 0) close(ctx->drm_fd);
+  ctx->drm_fd = -1;
   (void)hipFree(ctx->d_pos);
   (void)hipFree(ctx->d_rot);
   (void)hipFree(ctx->d_scale);
@@ -643,8 +662,16 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
     // a smaller table: the resident mesh ids (validated against the old one) must still be inside it
     uint32_t bad = 0, bad_ids = 0;
     if (int32_t rc = census(ctx, 0, ctx->n, &bad, &bad_ids, m)) return rc;
-    if (bad_ids)
-      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u resident instance(s) name a mesh >= the new table's %u entries; table unchanged", bad_ids, m);
+    if (bad_ids) {
+      // a new scene: table first, instances next (the documented order). The old instances cannot run against
+      // this table — they are no longer resident; a frame before the next upload fails with MIP_ERR_NOT_READY.
+      ctx->have_instances = false;
+      ctx->n = 0;
+      ctx->nonfinite_instances = 0;
+      for (auto& sl : ctx->slots) sl.status_dirty = true;
+      for (auto& sl : ctx->view_states) sl.status_dirty = true;
+      ctx->graph_generation++;
+    }
   }
   if (m) {
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_meshes, entries.data(), m * sizeof(mip::MeshEntry), hipMemcpyHostToDevice, ctx->stream));
@@ -922,7 +949,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
         uint32_t blocks = n * mip::kTriParts;
         const uint32_t max_blocks = (uint32_t)ctx->cu_count * 4u;  // resident as a whole at this kernel's 121 VGPRs (4 waves per SIMD)
         if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL(mip::mip_triangle_cull_parts_kernel, dim3(blocks), dim3(256), 0, stream, pa);
+        mip::launch_triangle_cull_parts(blocks, stream, pa);
       } else if (n <= ctx->tri_block_max) {
         // workgroup size: the register budget allows 16 waves per CU, so 1024 / 512 / 256 threads = 1 / 2 / 4
         // workgroups per CU; smaller workgroups wait less at the per-step barrier, larger ones finish a
@@ -934,15 +961,13 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
         const uint32_t per_cu = 2u * (1024u / tb);
         uint32_t blocks = n < (uint32_t)ctx->cu_count * per_cu ? n : (uint32_t)ctx->cu_count * per_cu;
         if (!blocks) blocks = 1u;
-        if (tb == 256u) hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<256>, dim3(blocks), dim3(256), 0, stream, t);
-        else if (tb == 512u) hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<512>, dim3(blocks), dim3(512), 0, stream, t);
-        else hipLaunchKernelGGL(mip::mip_triangle_cull_block_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, t);
+        mip::launch_triangle_cull_block(tb, blocks, stream, t);
       } else {
         MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));  // only the wave-per-command kernel hands out tickets
         uint32_t blocks = (n + 3u) / 4u;
         const uint32_t max_blocks = (uint32_t)ctx->cu_count * 8u;
         if (blocks > max_blocks) blocks = max_blocks;
-        hipLaunchKernelGGL(mip::mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, t);
+        mip::launch_triangle_cull_waves(blocks, stream, t);
       }
       MIP_HIP(ctx, hipGetLastError());
       // (re-compacting inside the workgroup kernels, by the last workgroup to finish, was measured: the
@@ -953,7 +978,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;
-        hipLaunchKernelGGL(mip::mip_recompact_kernel, dim3(1), dim3(1024), 0, stream, r);
+        mip::launch_recompact(stream, r);
       } else {  // many commands: counts per 1024, one block scans them, scatter
         mip::RecompactWideArgs r{};
         r.in_cmds = sl.d_tmp_cmds;
@@ -962,9 +987,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
         r.out_count = out->draw_count;
         r.block_base = sl.d_tmp_blocks;
         r.n_blocks = (n + 1023u) / 1024u;
-        hipLaunchKernelGGL(mip::mip_recompact_count_kernel, dim3(r.n_blocks), dim3(1024), 0, stream, r);
-        hipLaunchKernelGGL(mip::mip_recompact_scan_kernel, dim3(1), dim3(1024), 0, stream, r);
-        hipLaunchKernelGGL(mip::mip_recompact_scatter_kernel, dim3(r.n_blocks), dim3(1024), 0, stream, r);
+        mip::launch_recompact_wide(stream, r);
       }
       MIP_HIP(ctx, hipGetLastError());
     }
@@ -1729,6 +1752,76 @@ static MipContext::ExternalSemaphore* find_semaphore(MipContext* ctx, MipExterna
   return nullptr;
 }
 
+// ---- DRM sync object path (host functions on the stream) ----
+struct SemaphoreOp {
+  int drm_fd;
+  uint32_t handle, kind;
+  uint64_t value;
+  bool signal;
+  volatile uint32_t* error_word;  // host memory (the context's error words): a wait that expired is reported by the next mip_wait
+};
+constexpr int64_t kSemaphoreWaitNs = 10ll * 1000 * 1000 * 1000;  // bounded like every other wait in the library
+
+static void semaphore_host_fn(void* p) {
+  SemaphoreOp* op = static_cast<SemaphoreOp*>(p);
+  uint32_t handle = op->handle;
+  uint64_t point = op->value;
+  int rc = 0;
+  if (op->signal) {
+    if (op->kind == MIP_SEMAPHORE_TIMELINE) {
+      drm_syncobj_timeline_array a{};
+      a.handles = (uintptr_t)&handle;
+      a.points = (uintptr_t)&point;
+      a.count_handles = 1;
+      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL, &a);
+    } else {
+      drm_syncobj_array a{};
+      a.handles = (uintptr_t)&handle;
+      a.count_handles = 1;
+      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_SIGNAL, &a);
+    }
+  } else {
+    timespec now;
+    clock_gettime(CLOCK_MONOTONIC, &now);
+    const int64_t deadline = (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec + kSemaphoreWaitNs;
+    if (op->kind == MIP_SEMAPHORE_TIMELINE) {
+      drm_syncobj_timeline_wait w{};
+      w.handles = (uintptr_t)&handle;
+      w.points = (uintptr_t)&point;
+      w.timeout_nsec = deadline;
+      w.count_handles = 1;
+      w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;  // the point may not have been submitted yet
+      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_WAIT, &w);
+    } else {
+      drm_syncobj_wait w{};
+      w.handles = (uintptr_t)&handle;
+      w.timeout_nsec = deadline;
+      w.count_handles = 1;
+      w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;
+      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_WAIT, &w);
+      if (rc == 0) {  // a binary semaphore is consumed by its wait
+        drm_syncobj_array a{};
+        a.handles = (uintptr_t)&handle;
+        a.count_handles = 1;
+        (void)ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_RESET, &a);
+      }
+    }
+  }
+  if (rc != 0) *op->error_word = mip::kErrSemaphore;
+  delete op;
+}
+
+static int32_t enqueue_semaphore_op(MipContext* ctx, MipContext::ExternalSemaphore* s, uint64_t value, bool signal, hipStream_t stream) {
+  SemaphoreOp* op = new (std::nothrow) SemaphoreOp{ctx->drm_fd, s->drm_handle, s->kind, value, signal, ctx->h_error + 5};
+  if (!op) return fail(ctx, MIP_ERR_OUT_OF_MEMORY, "out of host memory");
+  const hipError_t e = hipLaunchHostFunc(stream, semaphore_host_fn, op);
+  if (e != hipSuccess) {
+    delete op;
+    return fail(ctx, MIP_ERR_DEVICE, "hipLaunchHostFunc failed: %s", hipGetErrorString(e));
+  }
+  return MIP_OK;
+}
+
 int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t kind, MipExternalSemaphore** out_semaphore) {
   if (out_semaphore) *out_semaphore = nullptr;
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
@@ -1739,13 +1832,32 @@ int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t k
   hd.type = kind == MIP_SEMAPHORE_TIMELINE ? hipExternalSemaphoreHandleTypeTimelineSemaphoreFd : hipExternalSemaphoreHandleTypeOpaqueFd;
   hd.handle.fd = fd;
   hipExternalSemaphore_t sem = nullptr;
-  const hipError_t e = hipImportExternalSemaphore(&sem, &hd);
-  if (e != hipSuccess || !sem)
-    return fail(ctx, MIP_ERR_DEVICE, "hipImportExternalSemaphore(%s) failed: %s", kind == MIP_SEMAPHORE_TIMELINE ? "TimelineSemaphoreFd" : "OpaqueFd",
-                hipGetErrorString(e));
-  auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind};
+  hipError_t e = std::getenv("MIP_TUNE_SEMAPHORE_VIA_DRM") ? hipErrorNotSupported : hipImportExternalSemaphore(&sem, &hd);
+  uint32_t drm_handle = 0;
+  if (e != hipSuccess || !sem) {
+    // The runtime refuses the handle type (ROCm 7.2, Linux: TimelineSemaphoreFd -> "invalid argument", OpaqueFd ->
+    // "operation not supported"). The fd itself is a kernel sync object: take it on a render node.
+    sem = nullptr;
+    (void)hipGetLastError();
+    if (ctx->drm_fd < 0) {
+      char node[64];
+      for (int k = 128; k < 192 && ctx->drm_fd < 0; ++k) {
+        snprintf(node, sizeof node, "/dev/dri/renderD%d", k);
+        ctx->drm_fd = open(node, O_RDWR | O_CLOEXEC);
+      }
+    }
+    drm_syncobj_handle h{};
+    h.fd = fd;
+    if (ctx->drm_fd < 0 || ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE, &h) != 0 || !h.handle)
+      return fail(ctx, MIP_ERR_DEVICE, "hipImportExternalSemaphore(%s) failed: %s; and the fd is not a DRM sync object either (%s)",
+                  kind == MIP_SEMAPHORE_TIMELINE ? "TimelineSemaphoreFd" : "OpaqueFd", hipGetErrorString(e),
+                  ctx->drm_fd < 0 ? "no render node could be opened" : "DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE refused it");
+    drm_handle = h.handle;
+    close(fd);  // imported: the fd belonged to the library from here on (the sync object lives on through the handle)
+  }
+  auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind, drm_handle};
   if (!entry) {
-    (void)hipDestroyExternalSemaphore(sem);
+    if (sem) (void)hipDestroyExternalSemaphore(sem);
     return fail(ctx, MIP_ERR_OUT_OF_MEMORY, "out of host memory");
   }
   ctx->semaphores.push_back(entry);
@@ -1753,15 +1865,27 @@ int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t k
   return MIP_OK;
 }
 
+int32_t mip_external_semaphore_on_device(MipContext* ctx, MipExternalSemaphore* semaphore) {
+  if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
+  if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
+  return s->sem ? 1 : 0;
+}
+
 int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint64_t value) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
-  hipExternalSemaphoreWaitParams p{};
-  p.params.fence.value = value;
   // the stream the NEXT frame will be enqueued on: that frame then starts only when the semaphore has been reached
-  MIP_HIP(ctx, hipWaitExternalSemaphoresAsync(&s->sem, &p, 1, ctx->slots[ctx->next_slot].stream));
+  hipStream_t stream = ctx->slots[ctx->next_slot].stream;
+  if (s->sem) {
+    hipExternalSemaphoreWaitParams p{};
+    p.params.fence.value = value;
+    MIP_HIP(ctx, hipWaitExternalSemaphoresAsync(&s->sem, &p, 1, stream));
+  } else if (int32_t rc = enqueue_semaphore_op(ctx, s, value, false, stream)) {
+    return rc;
+  }
   ctx->pending_async = true;
   return MIP_OK;
 }
@@ -1771,10 +1895,15 @@ int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, ui
   MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
-  hipExternalSemaphoreSignalParams p{};
-  p.params.fence.value = value;
   // behind the frame that was issued last (its slot's stream)
-  MIP_HIP(ctx, hipSignalExternalSemaphoresAsync(&s->sem, &p, 1, ctx->slots[ctx->last_slot].stream));
+  hipStream_t stream = ctx->slots[ctx->last_slot].stream;
+  if (s->sem) {
+    hipExternalSemaphoreSignalParams p{};
+    p.params.fence.value = value;
+    MIP_HIP(ctx, hipSignalExternalSemaphoresAsync(&s->sem, &p, 1, stream));
+  } else if (int32_t rc = enqueue_semaphore_op(ctx, s, value, true, stream)) {
+    return rc;
+  }
   ctx->pending_async = true;
   return MIP_OK;
 }
@@ -1786,7 +1915,12 @@ int32_t mip_release_external_semaphore(MipContext* ctx, MipExternalSemaphore* se
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
-  MIP_HIP(ctx, hipDestroyExternalSemaphore(s->sem));
+  if (s->sem) MIP_HIP(ctx, hipDestroyExternalSemaphore(s->sem));
+  if (s->drm_handle) {
+    drm_syncobj_destroy d{};
+    d.handle = s->drm_handle;
+    (void)ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_DESTROY, &d);
+  }
   ctx->semaphores.erase(ctx->semaphores.begin() + (long)at);
   delete s;
   return MIP_OK;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "instance_kernel.hpp"
+#include "triangle_args.hpp"
 
 #pragma clang fp contract(off)
 
@@ -19,21 +20,6 @@ namespace mip {
 // FMA; back-face = determinant of the xyw columns > 0; x/y NDC rejection after a true
 // divide — exactly what the oracle (orc_cull_triangles) fixes where GLSL leaves it open.
 
-struct TriangleArgs {
-  uint32_t* cmds;                 // compacted commands of the instance kernel; indexCount is rewritten
-  const uint32_t* count;          // number of commands (device)
-  const uint32_t* src_index_offset;
-  const float4* model;            // n x mat4 of the same frame
-  const float* vertices;          // consolidated positions, packed vec3
-  const uint32_t* indices;        // consolidated indices
-  uint32_t* out_indices;          // culled index stream (uvec3 out_index_buffer[])
-  unsigned long long capacity;    // in indices
-  uint32_t first_instance_base;
-  uint32_t* error_flag;
-  uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
-  uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
-  float pv[16];
-};
 
 
 __device__ __forceinline__ void glsl_mat4_mul_vec4(const float (&m)[16], float x, float y, float z, float w, float (&o)[4]) {
@@ -226,12 +212,6 @@ __device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, uint
   if (tid == 0) *out_count = s_running;
 }
 
-struct RecompactArgs {
-  const uint32_t* in_cmds;
-  const uint32_t* in_count;
-  uint32_t* out_cmds;
-  uint32_t* out_count;
-};
 
 // Its own launch after the wave-per-command kernel (large frames).
 __global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
@@ -243,14 +223,6 @@ __global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs
 // Large frames: the same re-compaction over many workgroups, as three small launches — per-block
 // survivor counts, one block scanning them, the scatter (a single workgroup takes 44 us at 27 k
 // commands and 0.4 ms at 258 k).
-struct RecompactWideArgs {
-  const uint32_t* in_cmds;
-  const uint32_t* in_count;
-  uint32_t* out_cmds;
-  uint32_t* out_count;
-  uint32_t* block_base;   // one word per 1024 commands: survivors in the block, then their exclusive prefix
-  uint32_t n_blocks;
-};
 
 __global__ __launch_bounds__(1024) void mip_recompact_count_kernel(const RecompactWideArgs a) {
   __shared__ uint32_t s_totals[16];
@@ -418,14 +390,7 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
 // publishes its survivor count as one tagged granule, reads the <= 15 earlier parts of its command (one round trip
 // in the common case), and writes its survivors behind theirs: the stream keeps mesh order, exactly as the
 // one-wave and one-workgroup kernels produce it. The last part writes the command's final indexCount.
-constexpr uint32_t kTriParts = 16;
-constexpr uint32_t kTriPartMaxT = 8;  // triangles per thread and part: commands up to 16 * 256 * 8 = 32 768 triangles
 
-struct TrianglePartsArgs {
-  TriangleArgs t;
-  unsigned long long* part_status;  // [commands][kTriParts] granules {epoch : 32 | survivors : 32}
-  uint32_t epoch;                   // unique per launch on this frame slot, never 0
-};
 
 __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const TrianglePartsArgs pa) {
   const TriangleArgs& a = pa.t;

@@ -255,6 +255,13 @@ class InstancePipeline:
         self._check(self._lib.mip_import_external_semaphore_fd(self._ctx, int(fd), kind, C.byref(h)))
         return h.value
 
+    def external_semaphore_on_device(self, semaphore):
+        """True: the HIP runtime imported the semaphore (device-side waits/signals); False: the DRM sync object path."""
+        rc = self._lib.mip_external_semaphore_on_device(self._ctx, semaphore)
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
+
     def wait_external(self, semaphore, value=0):
         """The next frame's stream waits on the device until the semaphore reaches `value`."""
         self._check(self._lib.mip_wait_external(self._ctx, semaphore, int(value)))

@@ -118,7 +118,8 @@ class DrawListExchange:
         """Block until the frames issued so far are done. If the LAST one overflowed its tightened chunk,
         repeat its all-gather + merge at full capacity (collective: the overflow is visible in the headers
         every rank gathered, so every rank takes this branch together). Returns True if it had to."""
-        self._check_stream("complete")  # a repair issues an all-gather: it must land on the pipeline's stream
+        if self._in_flight:
+            self._check_stream("complete")  # a repair issues an all-gather: it must land on the pipeline's stream
         in_flight, self._in_flight = self._in_flight, 0
         try:
             self.pipe.wait()
@@ -221,6 +222,10 @@ class PipelinedExchange:
 
     def tighten(self, margin=1.0625):
         return [ex.tighten(margin) for ex in self.exchanges]
+
+    def merged_draw_list(self, k):
+        """Slot k's merged list on the host (completes — and if need be repairs — its last frame first)."""
+        return self._under(k, self.exchanges[k].merged_draw_list)
 
     def close(self):
         for p in self.pipes:

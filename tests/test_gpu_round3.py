@@ -313,13 +313,15 @@ def test_pipelined_exchange_repairs_an_overflow_under_its_own_stream(ra, oracle_
                 px.step(f, [None, None])
             px.wait()
             assert sum(ex.retries for ex in px.exchanges) >= 1
-            for ex in px.exchanges:
-                cmds, total, index_total = px._under(px.exchanges.index(ex), ex.merged_draw_list)
+            for k in range(2):
+                cmds, total, index_total = px.merged_draw_list(k)
                 assert total == want_b["draw_count"] and index_total == want_b["draw_index_total"], (wire, total)
                 assert cmds.tobytes() == want_b["draw_cmds"].tobytes(), f"wire={wire}"
-            # complete() refuses to run a repair on a foreign stream instead of racing
+            # with a frame in flight, complete() refuses to run (a possible repair) on a foreign stream instead of racing
+            px.step(frame_a, [None, None])
             with pytest.raises(ValueError):
-                px.exchanges[0].complete()
+                px.exchanges[px.last].complete()
+            px.wait()
             px.close()
     finally:
         dist.destroy_process_group()
@@ -348,10 +350,15 @@ def test_device_upload_rejects_mesh_ids_outside_the_table(ra):
         p.set_instances_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), good.data_ptr(), s["n"])
         got = p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))
         assert got["draw_count"] > 0
-        # a smaller table afterwards: the resident ids are checked against it at the next upload of either
+        # a smaller table afterwards (a new scene: table first, instances next): ids that fall outside it make the
+        # old instances non-resident instead of letting a frame gather outside the table
+        p.set_mesh_table(s["meshes"][:10])
         with pytest.raises(ra.MipError) as e:
-            p.set_mesh_table(s["meshes"][:10])
-        assert e.value.code == -1
+            p.run_host(s["planes"], s["cam_pos"])
+        assert e.value.code == -6
+        p.set_mesh_table(s["meshes"])
+        p.set_instances_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), good.data_ptr(), s["n"])
+        assert p.run_host(s["planes"], s["cam_pos"], want=("draw_cmds",))["draw_count"] == got["draw_count"]
 
 
 # ---- row f-2, the semaphore half -------------------------------------------------------------------------------
@@ -408,6 +415,20 @@ class _SyncObj:
         buf = bytearray(self.struct.pack("QQII", C.addressof(h), C.addressof(p), 1, 0))
         self.fcntl.ioctl(self.fd, _drm_iowr(0xCD, 24), buf)  # DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL
 
+    def wait_binary(self, seconds):
+        """True once the (binary) sync object has a signalled fence."""
+        import ctypes as C
+        import time
+
+        h = (C.c_uint32 * 1)(self.handle)
+        deadline = int((time.monotonic() + seconds) * 1e9)
+        buf = bytearray(self.struct.pack("QqIIII", C.addressof(h), deadline, 1, 2, 0, 0))  # flags 2 = WAIT_FOR_SUBMIT
+        try:
+            self.fcntl.ioctl(self.fd, _drm_iowr(0xC3, 32), buf)  # DRM_IOCTL_SYNCOBJ_WAIT
+            return True
+        except OSError:
+            return False
+
     def close(self):
         if self.fd >= 0:
             os.close(self.fd)
@@ -452,12 +473,13 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
                 call()
             assert e.value.code == -1
         # -- the hand-over against a real kernel sync object --
-        so = _SyncObj()
-        if so.fd < 0:
-            notes.append(f"no DRM sync object available ({so.why}): hand-over not exercised")
-        else:
+        for timeline in (True, False):
+            so = _SyncObj()  # a fresh kernel object per kind
+            if so.fd < 0:
+                notes.append(f"no DRM sync object available ({so.why}): hand-over not exercised")
+                continue
             try:
-                for timeline in (True, False):
+                if True:
                     fd = so.export_fd()
                     try:
                         sem = p.import_external_semaphore_fd(fd, timeline=timeline)
@@ -466,7 +488,8 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
                         notes.append(f"DRM syncobj fd as {'Timeline' if timeline else 'Opaque'}Fd -> {e}")
                         os.close(fd)
                         continue
-                    notes.append(f"DRM syncobj fd as {'Timeline' if timeline else 'Opaque'}Fd -> imported")
+                    notes.append(f"DRM syncobj fd as {'Timeline' if timeline else 'Opaque'}Fd -> imported, "
+                                 f"{'device-side (HIP runtime)' if p.external_semaphore_on_device(sem) else 'host functions on the stream (DRM sync object)'}")
                     with pytest.raises(ra.MipError):  # a handle belongs to the context that imported it
                         other.release_external_semaphore(sem)
                     if timeline:
@@ -489,6 +512,17 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
                         assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
                         p.wait()
                         notes.append("timeline hand-over: wait(1) -> frame -> signal(2) observed through the DRM sync object")
+                    else:
+                        cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+                        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+                        torch.cuda.synchronize()
+                        assert not so.wait_binary(0.05), "a fresh binary semaphore is unsignalled"
+                        p.run_device(make_frame(s["planes"], s["cam_pos"]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), async_=True)
+                        p.signal_external(sem)
+                        assert so.wait_binary(10.0), "the binary signal behind the frame never arrived"
+                        assert int(scal[0].item()) == want["draw_count"]
+                        p.wait()
+                        notes.append("binary hand-over: frame -> signal observed through the DRM sync object")
                     p.release_external_semaphore(sem)
                     with pytest.raises(ra.MipError):
                         p.release_external_semaphore(sem)            # released once
