@@ -38,32 +38,67 @@ __device__ __forceinline__ void triangle_fetch(const float* vertices, long long 
   }
 }
 
-// One triangle of generate_work.comp:132-155: true = culled (back-facing or beyond one x/y bound).
+// clip.xyw of one vertex: pv * (model * vec4(v, 1)) (generate_work.comp:132-136) as column combinations left to
+// right, no FMA — the x, y and w rows only: clip.z never enters the tests below, so it is never computed.
 // kAffine: the caller has checked that row 3 of `model` is (0,0,0,1) and that the geometry holds
 // only finite positions. Then world.w = ((0*x + 0*y) + 0*z) + 1 is exactly 1 and pv[:,3] * world.w
-// is exactly pv[:,3], so that row and those four products are skipped: same bits, 126 instead
-// of 156 flops per triangle.
+// is exactly pv[:,3], so that row and those products are skipped: same bits, fewer flops.
+//
+// A/B build -DMIP_TRI_PACKED: rows 0 and 1 of a column-major matrix are adjacent (model[c*4 + 0], model[c*4 + 1]), so
+// the two rows of every column combination can be written as ONE two-wide operation (v_pk_mul_f32 / v_pk_add_f32:
+// element-wise IEEE multiply and add, each rounded on its own — the bits of two scalar instructions; the coordinate is
+// broadcast by op_sel, no register moves). 24 instead of 36 vector instructions per vertex, 120 instead of 165 per
+// 64-triangle step — and SLOWER: 1.07 against 1.03 ms for the 100 k frame (profiles/r03_triangle_packed_ab.txt). A
+// packed f32 instruction occupies the SIMD for two passes; the kernel is bound by VALU issue TIME (95 % busy), which
+// counts flops, not instructions. So the product build keeps one instruction per flop.
+typedef float tri_v2f __attribute__((ext_vector_type(2)));
 template <bool kAffine>
-__device__ __forceinline__ bool triangle_test(const float (&model)[16], const float (&pv)[16], const float (&v)[9]) {
-  float clip[3][4];
+__device__ __forceinline__ void vertex_clip_xyw(const float (&model)[16], const float (&pv)[16], float x, float y, float z, float (&c)[3]) {
+#ifdef MIP_TRI_PACKED
+  auto col01 = [](const float (&m)[16], int col) { return tri_v2f{m[col * 4 + 0], m[col * 4 + 1]}; };
+  if constexpr (kAffine) {
+    const tri_v2f w01 = col01(model, 0) * x + col01(model, 1) * y + col01(model, 2) * z + col01(model, 3);
+    const float w2 = model[0 * 4 + 2] * x + model[1 * 4 + 2] * y + model[2 * 4 + 2] * z + model[3 * 4 + 2];
+    const tri_v2f cxy = col01(pv, 0) * w01.x + col01(pv, 1) * w01.y + col01(pv, 2) * w2 + col01(pv, 3);
+    c[0] = cxy.x; c[1] = cxy.y;
+    c[2] = pv[0 * 4 + 3] * w01.x + pv[1 * 4 + 3] * w01.y + pv[2 * 4 + 3] * w2 + pv[3 * 4 + 3];
+  } else {
+    auto col23 = [](const float (&m)[16], int col) { return tri_v2f{m[col * 4 + 2], m[col * 4 + 3]}; };
+    const tri_v2f w01 = col01(model, 0) * x + col01(model, 1) * y + col01(model, 2) * z + col01(model, 3) * 1.0f;
+    const tri_v2f w23 = col23(model, 0) * x + col23(model, 1) * y + col23(model, 2) * z + col23(model, 3) * 1.0f;
+    const tri_v2f cxy = col01(pv, 0) * w01.x + col01(pv, 1) * w01.y + col01(pv, 2) * w23.x + col01(pv, 3) * w23.y;
+    c[0] = cxy.x; c[1] = cxy.y;
+    c[2] = pv[0 * 4 + 3] * w01.x + pv[1 * 4 + 3] * w01.y + pv[2 * 4 + 3] * w23.x + pv[3 * 4 + 3] * w23.y;
+  }
+#else
+  constexpr int kRows[3] = {0, 1, 3};
+  if constexpr (kAffine) {
+    float world[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if constexpr (kAffine) {
-      const float x = v[k * 3 + 0], y = v[k * 3 + 1], z = v[k * 3 + 2];
-      float world[3];
+    for (int r = 0; r < 3; ++r) world[r] = model[0 * 4 + r] * x + model[1 * 4 + r] * y + model[2 * 4 + r] * z + model[3 * 4 + r];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) world[r] = model[0 * 4 + r] * x + model[1 * 4 + r] * y + model[2 * 4 + r] * z + model[3 * 4 + r];
+    for (int q = 0; q < 3; ++q) {
+      const int r = kRows[q];
+      c[q] = pv[0 * 4 + r] * world[0] + pv[1 * 4 + r] * world[1] + pv[2 * 4 + r] * world[2] + pv[3 * 4 + r];
+    }
+  } else {
+    float world[4];
+    glsl_mat4_mul_vec4(model, x, y, z, 1.0f, world);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) clip[k][r] = pv[0 * 4 + r] * world[0] + pv[1 * 4 + r] * world[1] + pv[2 * 4 + r] * world[2] + pv[3 * 4 + r];
-    } else {
-      float world[4];
-      glsl_mat4_mul_vec4(model, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], 1.0f, world);
-      glsl_mat4_mul_vec4(pv, world[0], world[1], world[2], world[3], clip[k]);
+    for (int q = 0; q < 3; ++q) {
+      const int r = kRows[q];
+      c[q] = pv[0 * 4 + r] * world[0] + pv[1 * 4 + r] * world[1] + pv[2 * 4 + r] * world[2] + pv[3 * 4 + r] * world[3];
     }
   }
-  const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][3];
-  const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][3];
-  const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][3];
+#endif
+}
+
+// One triangle of generate_work.comp:137-155 from the clip.xyw of its corners: true = culled (back-facing or
+// beyond one x/y bound).
+__device__ __forceinline__ bool triangle_cull_clip(const float (&clip)[3][3]) {
+  const float a00 = clip[0][0], a01 = clip[0][1], a02 = clip[0][2];
+  const float a10 = clip[1][0], a11 = clip[1][1], a12 = clip[1][2];
+  const float a20 = clip[2][0], a21 = clip[2][1], a22 = clip[2][2];
   const float det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) + a20 * (a01 * a12 - a11 * a02);
   bool cull = det > 0.0f;
   // ndc = clip.xy / clip.w compared with -1 and 1 (generate_work.comp:143-155), without dividing:
@@ -77,8 +112,8 @@ __device__ __forceinline__ bool triangle_test(const float (&model)[16], const fl
   bool xl = true, xg = true, yl = true, yg = true;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const uint32_t sw = __float_as_uint(clip[k][3]) & 0x80000000u;
-    const float w = fabsf(clip[k][3]);
+    const uint32_t sw = __float_as_uint(clip[k][2]) & 0x80000000u;
+    const float w = fabsf(clip[k][2]);
     const float x = __uint_as_float(__float_as_uint(clip[k][0]) ^ sw);
     const float y = __uint_as_float(__float_as_uint(clip[k][1]) ^ sw);
     xl = xl && (x < -w);
@@ -87,6 +122,14 @@ __device__ __forceinline__ bool triangle_test(const float (&model)[16], const fl
     yg = yg && (y > w);
   }
   return cull || xl || xg || yl || yg;
+}
+
+template <bool kAffine>
+__device__ __forceinline__ bool triangle_test(const float (&model)[16], const float (&pv)[16], const float (&v)[9]) {
+  float clip[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vertex_clip_xyw<kAffine>(model, pv, v[k * 3 + 0], v[k * 3 + 1], v[k * 3 + 2], clip[k]);
+  return triangle_cull_clip(clip);
 }
 
 __device__ __forceinline__ bool triangle_culled(bool affine, const float (&model)[16], const float (&pv)[16], const float* vertices,

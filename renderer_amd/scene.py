@@ -308,10 +308,32 @@ def _torus_mesh(n_vertices, n_triangles, aabb_min, aabb_max):
     return pos.astype(np.float32), tris[order].astype(np.uint32)
 
 
-def make_geometry(meshes):
+def _first_use_order(pos, tris):
+    """Renumbers the vertices in the order the triangle list first uses them (what meshoptimizer's
+    optimizeVertexFetch produces, and roughly what exporters write); unused vertices keep their relative order
+    behind the used ones. Same surface, same triangle order."""
+    flat = tris.reshape(-1).astype(np.int64)
+    _, first = np.unique(flat, return_index=True)
+    used = flat[np.sort(first)]
+    rest = np.setdiff1d(np.arange(len(pos), dtype=np.int64), used, assume_unique=False)
+    order = np.concatenate([used, rest])
+    new_id = np.empty(len(pos), np.int64)
+    new_id[order] = np.arange(len(pos), dtype=np.int64)
+    return pos[order], new_id[tris].astype(np.uint32)
+
+
+def make_geometry(meshes, ordering="rows"):
     """Consolidated position and index buffers matching a mesh table's vertex_offset /
     index_offset / index_len (what consolidate_mesh_buffers builds). Returns (vertices (V,3) f32,
-    indices (I,) u32). LOD k keeps an evenly spaced subset of LOD 0's triangles."""
+    indices (I,) u32). LOD k keeps an evenly spaced subset of LOD 0's triangles.
+
+    ordering: "rows" — the torus grid as generated: all "lower" triangles of the grid, then all "upper" ones,
+    vertices row-major: a triangle's corners are a grid row (~sqrt(V) vertices) apart. "strips" — the same
+    surface listed quad by quad along the strips with the vertices renumbered in first-use order: the layout
+    of a vertex-cache/vertex-fetch optimised mesh. "shuffled" — the triangles of "rows" in random order: no
+    locality at all (every 64-triangle step spans the whole mesh)."""
+    if ordering not in ("rows", "strips", "shuffled"):
+        raise ValueError(ordering)
     m = len(meshes)
     voff = meshes["vertex_offset"].astype(np.int64)
     order = np.argsort(voff, kind="stable")
@@ -330,8 +352,16 @@ def make_geometry(meshes):
     for k in range(m):
         t0 = int(meshes["index_len"][k, 0]) // 3
         pos, tris = _torus_mesh(int(vcount[k]), max(t0, 1), meshes["aabb_min"][k], meshes["aabb_max"][k])
-        vertices[voff[k] : voff[k] + vcount[k]] = pos[: vcount[k]]
         tris = np.minimum(tris, vcount[k] - 1)
+        pos = pos[: vcount[k]]
+        if ordering == "strips":
+            half = len(tris) // 2  # _torus_mesh lists the lower triangle of every quad, then the upper ones
+            if len(tris) == 2 * half and half > 0 and t0 >= len(tris):
+                tris = np.stack([tris[:half], tris[half:]], axis=1).reshape(-1, 3)  # quad by quad
+            pos, tris = _first_use_order(pos, tris)
+        elif ordering == "shuffled":
+            tris = tris[np.random.default_rng(1234 + k).permutation(len(tris))]
+        vertices[voff[k] : voff[k] + vcount[k]] = pos
         for l in range(int(meshes["n_lods"][k])):
             tl = int(meshes["index_len"][k, l]) // 3
             if tl == 0:

@@ -91,6 +91,35 @@ def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
     assert np.array_equal(got_out, want_out), mode
 
 
+@pytest.mark.parametrize("ordering", ["rows", "strips", "shuffled"])
+@pytest.mark.parametrize("config,n", [(3, 7000), (2, 1500)])
+def test_wave_kernel_vertex_ring_on_every_mesh_layout(ra, oracle_mod, monkeypatch, ordering, config, n):
+    """The wave-per-command kernel transforms a step's vertex range once into its LDS ring when that is cheaper than
+    the per-corner path. The bytes must not depend on which path a step took: the same surfaces listed row by row
+    (ranges of a few hundred vertices: ring, window carried from step to step), as first-use-ordered strips (the layout
+    of an optimised mesh), and with shuffled triangles (every step spans the mesh: per-corner path), with non-finite
+    positions (literal chain), a NaN matrix, tiny meshes whose window runs past their vertices, and the last mesh of
+    the consolidated buffer (the ring loads ahead of the indices it has seen: clamped at the buffer's end)."""
+    monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+    monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "0")
+    s = ra.scene.make_scene(config, n=n, all_visible=(config == 2))
+    s["pos"][11, 1] = np.nan
+    vertices, indices = ra.scene.make_geometry(s["meshes"], ordering=ordering)
+    pv = ra.scene.default_pv()
+    r0 = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
+    capacity = r0["draw_index_total"] + 3
+    for poison in (False, True):
+        if poison:  # non-finite positions switch the affine shortcut off for the whole geometry
+            vertices = vertices.copy()
+            vertices[min(10, len(vertices) - 1), 0] = np.inf
+            vertices[len(vertices) // 2, 2] = np.nan
+        r, want_cmds, want_out = _oracle(oracle_mod, s, vertices, indices, pv, capacity, first_instance_base=5)
+        got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, frames=2, first_instance_base=5)
+        assert count == len(want_cmds) and total == r["draw_index_total"], (ordering, poison)
+        assert got_cmds.tobytes() == want_cmds.tobytes(), (ordering, poison)
+        assert np.array_equal(got_out, want_out), (ordering, poison)
+
+
 def test_triangle_cull_special_instances_and_bases(ra, oracle_mod):
     s = ra.scene.make_scene(3, n=2000, all_visible=True)
     s["pos"][5, 0] = np.nan          # NaN model matrix: every comparison is false, so every triangle survives

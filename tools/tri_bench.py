@@ -14,9 +14,12 @@ from renderer_amd.pipeline import make_frame
 
 config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 n = int(sys.argv[2]) if len(sys.argv) > 2 else None
+ordering = sys.argv[3] if len(sys.argv) > 3 else "rows"  # rows | strips | shuffled (scene.make_geometry)
 s = scene.make_scene(config, n=n)
 n = s["n"]
-vertices, indices = scene.make_geometry(s["meshes"])
+if os.environ.get("TRI_BENCH_ONE_LOD") == "1":  # every command walks LOD 0 (dense vertex use)
+    s["meshes"]["n_lods"][:] = 1
+vertices, indices = scene.make_geometry(s["meshes"], ordering=ordering)
 dev = torch.device("cuda", 0)
 p = renderer_amd.InstancePipeline(n, len(s["meshes"]))
 p.set_mesh_table(s["meshes"])
