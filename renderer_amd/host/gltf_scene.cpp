@@ -1,7 +1,10 @@
 // gltf_scene.cpp — see gltf_scene.hpp.
 #include "gltf_scene.hpp"
+#include "simplify_sloppy.hpp"
 
+#include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -250,7 +253,25 @@ Document open_document(const std::string& path) {
       if (comma == std::string::npos) throw std::runtime_error("gltf: bad data uri");
       d.buffers.push_back(base64_decode(uri->str, comma + 1));
     } else {
-      d.buffers.push_back(read_file(dirname_of(path) + "/" + uri->str));
+      // an untrusted .gltf must not make the extractor read arbitrary local files into its output: the buffer has to
+      // live in (or below) the asset's own directory — no absolute path, no scheme, no ".." component, and the
+      // resolved path (symbolic links followed) must still be inside that directory
+      const std::string& u = uri->str;
+      bool bad = u[0] == '/' || u[0] == '\\' || u.find(':') != std::string::npos;
+      for (size_t at = 0; !bad && at <= u.size();) {
+        size_t end = u.find_first_of("/\\", at);
+        if (end == std::string::npos) end = u.size();
+        if (u.compare(at, end - at, "..") == 0) bad = true;
+        at = end + 1;
+      }
+      if (bad) throw std::runtime_error("gltf: buffer uri must be a data: uri or a file path relative to the asset, inside its directory");
+      const std::string dir = dirname_of(path), full = dir + "/" + u;
+      char real_dir[PATH_MAX], real_file[PATH_MAX];
+      if (!realpath(dir.c_str(), real_dir) || !realpath(full.c_str(), real_file)) throw std::runtime_error("gltf: cannot open " + full);
+      const size_t dl = std::strlen(real_dir);
+      if (std::strncmp(real_dir, real_file, dl) != 0 || (real_file[dl] != '/' && dl > 1))
+        throw std::runtime_error("gltf: buffer uri resolves outside the asset's directory");
+      d.buffers.push_back(read_file(real_file));
     }
   }
   return d;
@@ -423,24 +444,17 @@ void visit_node(const Document& d, size_t node_index, Scene& out, int depth, siz
         if (v >= positions.count) throw std::runtime_error("gltf: index " + std::to_string(v) + " outside the primitive's " + std::to_string(positions.count) + " positions");
         lod0[k] = v;
       }
-      // LOD chain (:740-753): LOD 0 + up to five reduced levels kept while they shrink and are non-empty
+      // LOD chain (:739-753): LOD 0 + up to five levels from simplify_sloppy, each kept only if it came out shorter
+      // than LOD 0 and non-empty. The length of a level is whatever the simplifier returns (at most the target), so
+      // index_len[lod] — hence indexCount and the running firstIndex of cull_pass — is data-dependent.
       std::vector<std::vector<uint32_t>> lods;
       lods.push_back(lod0);
-      const size_t tris0 = lod0.size() / 3;
+      const float* prim_positions = out.vertices.data() + (size_t)m.vertex_offset * 3;
       for (int x = 1; x < 6; ++x) {
         const float factor = std::pow(0.5f, (float)x);
-        size_t target = (size_t)((float)lod0.size() * factor);
-        target -= target % 3;
-        if (target == 0 || target >= lod0.size()) continue;
-        std::vector<uint32_t> lod(target);
-        const size_t tris = target / 3;
-        for (size_t t = 0; t < tris; ++t) {
-          const size_t src = (t * tris0) / tris;
-          lod[t * 3 + 0] = lod0[src * 3 + 0];
-          lod[t * 3 + 1] = lod0[src * 3 + 1];
-          lod[t * 3 + 2] = lod0[src * 3 + 2];
-        }
-        lods.push_back(std::move(lod));
+        const size_t target = (size_t)((float)lod0.size() * factor);  // `(indices.len() as f32 * factor) as usize`
+        std::vector<uint32_t> res = simplify_sloppy(lod0, prim_positions, (size_t)positions.count, target);
+        if (res.size() < lod0.size() && !res.empty()) lods.push_back(std::move(res));
       }
       m.n_lods = (uint32_t)lods.size();
       for (size_t l = 0; l < lods.size(); ++l) {

@@ -112,3 +112,29 @@ def write_glb(path):
         f.write(struct.pack("<I4s", len(js), b"JSON") + js)
         f.write(struct.pack("<I4s", len(blob), b"BIN\0") + blob)
     return expected
+
+
+def write_simple(path, primitives):
+    """One scene, one textured node per (positions, indices) pair — for tests that only care about the geometry."""
+    blob = bytearray()
+    views, accessors, nodes, meshes = [], [], [], []
+    for k, (pos, idx) in enumerate(primitives):
+        pos = np.ascontiguousarray(pos, np.float32)
+        idx = np.ascontiguousarray(idx, np.uint32)
+        for data, acc in ((pos.tobytes(), {"componentType": 5126, "count": len(pos), "type": "VEC3", "min": pos.min(0).tolist(), "max": pos.max(0).tolist()}),
+                          (idx.tobytes(), {"componentType": 5125, "count": len(idx), "type": "SCALAR"})):
+            while len(blob) % 4:
+                blob.append(0)
+            views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+            blob.extend(data)
+            accessors.append(dict(acc, bufferView=len(views) - 1))
+        meshes.append({"primitives": [{"attributes": {"POSITION": 2 * k}, "indices": 2 * k + 1, "material": 0}]})
+        nodes.append({"name": f"n{k}", "mesh": k, "translation": [float(3 * k), 0.0, 10.0]})
+    gltf = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}], "nodes": nodes, "meshes": meshes,
+        "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}, "normalTexture": {"index": 0}}],
+        "textures": [{"source": 0}], "images": [{"uri": "albedo.png"}], "accessors": accessors, "bufferViews": views,
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()}],
+    }
+    with open(path, "w") as f:
+        json.dump(gltf, f)

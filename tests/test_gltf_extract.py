@@ -34,6 +34,22 @@ def read_scene(path):
     return dict(n=int(n), meshes=meshes, pos=pos, rot=rot, scale=scale, mesh_id=mesh_id, vertices=vertices, indices=indices)
 
 
+def _target(n, x):
+    return int(np.float32(n) * np.float32(0.5) ** np.float32(x))  # `(indices.len() as f32 * factor) as usize`
+
+
+def _lod_chain(positions, indices):
+    """What the loader keeps, from the independent numpy restatement of the simplifier (tests/simplify_sloppy_np.py)."""
+    from simplify_sloppy_np import simplify_sloppy
+
+    out = [np.asarray(indices, np.uint32)]
+    for x in range(1, 6):
+        res = simplify_sloppy(indices, positions, _target(len(indices), x))
+        if 0 < len(res) < len(indices):
+            out.append(res)
+    return out
+
+
 def _extract(src, copies=None):
     if not os.path.exists(EXTRACT):
         _build()
@@ -64,20 +80,15 @@ def test_extractor_follows_the_reference_loader(container):
     m = s["meshes"]
     assert np.array_equal(m["aabb_min"][0], big_pos.min(0)) and np.array_equal(m["aabb_max"][0], big_pos.max(0))
     assert np.array_equal(m["aabb_min"][1], med_pos.min(0)) and np.array_equal(m["aabb_max"][1], med_pos.max(0))
-    # LOD chain: len * 0.5^x rounded down to whole triangles, kept while it shrinks
-    def chain(n):
-        out = [n]
-        for x in range(1, 6):
-            t = int(np.float32(n) * np.float32(0.5) ** np.float32(x))
-            t -= t % 3
-            if 0 < t < n:
-                out.append(t)
-        return out
-    for k, idx in ((0, big_idx), (1, med_idx), (2, big_idx)):
-        want = chain(len(idx))
-        assert m["n_lods"][k] == len(want) and m["index_len"][k, : len(want)].tolist() == want
-        off0 = int(m["index_offset"][k, 0])
-        assert np.array_equal(s["indices"][off0 : off0 + len(idx)], idx)      # u16 and u32 sources
+    # LOD chain (scene_loader.rs:739-753): simplify_sloppy(indices, positions, len * 0.5^x) for x = 1..5, a level kept
+    # only if it is shorter than LOD 0 and non-empty; its length is whatever the simplifier returns, not the target
+    for k, (p_, idx) in ((0, (big_pos, big_idx)), (1, (med_pos, med_idx)), (2, (big_pos, big_idx))):
+        want = _lod_chain(p_, idx)
+        assert m["n_lods"][k] == len(want), (k, m["n_lods"][k], [len(w) for w in want])
+        for l, w in enumerate(want):
+            off = int(m["index_offset"][k, l])
+            assert m["index_len"][k, l] == len(w) and np.array_equal(s["indices"][off : off + len(w)], w), (k, l)   # u16 and u32 sources
+    assert m["n_lods"][0] >= 3 and any(m["index_len"][0, l] < _target(len(big_idx), l) for l in range(1, int(m["n_lods"][0])))
     assert m["vertex_offset"].tolist() == [0, len(big_pos), len(big_pos) + len(med_pos)]
     assert np.array_equal(s["vertices"][: len(big_pos)], big_pos)
     assert np.array_equal(s["vertices"][len(big_pos) : len(big_pos) + len(med_pos)], med_pos)  # strided view
@@ -86,6 +97,58 @@ def test_extractor_follows_the_reference_loader(container):
     for (o0, l0), (o1, _) in zip(flat, flat[1:]):
         assert o0 + l0 == o1
     assert flat[-1][0] + flat[-1][1] == len(s["indices"])
+
+
+def test_lod_levels_are_what_the_simplifier_returns_not_the_target():
+    """VERDICT r02 'missing 1': index_len[lod >= 1] feeds indexCount and the running firstIndex, so the LODs must be the
+    simplifier's output (data-dependent length <= target; dropped when empty), not a fixed-size stand-in. Shapes that
+    exercise the search: a dense torus (levels shorter than their targets), a sparse primitive — 120 positions, 4
+    triangles — whose every level comes out empty and is DROPPED, a flat plate (one grid layer: many duplicate
+    triangles to filter), two tori in one primitive (cells shared between surfaces), and a needle-thin stretched mesh
+    (the grid is isotropic: most cells empty). The C++ extractor and the numpy restatement must agree index for index."""
+    rng = np.random.default_rng(7)
+    torus_pos, torus_idx = gltf_fixture.torus(40, 25)                                 # 1000 positions, 2000 triangles
+    sparse_pos = torus_pos[:120]
+    sparse_idx = np.array([0, 1, 30, 1, 31, 30, 60, 61, 90, 61, 91, 90], np.uint32)
+    gx, gy = np.meshgrid(np.arange(20), np.arange(15), indexing="ij")
+    plate_pos = np.stack([gx.ravel() * 0.1, np.zeros(300), gy.ravel() * 0.1], 1).astype(np.float32)
+    q = (gx[:-1, :-1] * 15 + gy[:-1, :-1]).ravel()
+    plate_idx = np.concatenate([np.stack([q, q + 15, q + 16], 1), np.stack([q, q + 16, q + 1], 1)]).astype(np.uint32).ravel()
+    t2_pos, t2_idx = gltf_fixture.torus(16, 12, (0.5, 0.5, 0.5))
+    two_pos = np.concatenate([t2_pos, t2_pos + np.float32([0.2, 0.1, 0.0])]).astype(np.float32)
+    two_idx = np.concatenate([t2_idx, t2_idx + len(t2_pos)]).astype(np.uint32)
+    thin_pos, thin_idx = gltf_fixture.torus(30, 8, (5.0, 0.02, 0.02))
+    noisy_pos = (torus_pos + rng.normal(0, 0.003, torus_pos.shape)).astype(np.float32)
+    prims = [(torus_pos, torus_idx), (sparse_pos, sparse_idx), (plate_pos, plate_idx), (two_pos, two_idx), (thin_pos, thin_idx),
+             (noisy_pos, torus_idx)]
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "lods.gltf")
+        gltf_fixture.write_simple(src, prims)
+        r, out = _extract(src)
+        assert r.returncode == 0, r.stderr
+        s = read_scene(out)
+    m = s["meshes"]
+    assert s["n"] == len(prims)
+    shorter = dropped = 0
+    for k, (p_, idx) in enumerate(prims):
+        want = _lod_chain(p_, idx)
+        assert m["n_lods"][k] == len(want), (k, int(m["n_lods"][k]), [len(w) for w in want])
+        for l, w in enumerate(want):
+            off = int(m["index_offset"][k, l])
+            assert m["index_len"][k, l] == len(w), (k, l, int(m["index_len"][k, l]), len(w))
+            assert np.array_equal(s["indices"][off : off + len(w)], w), (k, l)
+            assert len(w) % 3 == 0 and (l == 0 or len(w) <= _target(len(idx), 1))
+        shorter += sum(1 for l in range(1, len(want)) if len(want[l]) < _target(len(idx), l) - 2)
+        dropped += 5 - (len(want) - 1)
+    assert m["n_lods"][1] <= 2                      # the sparse primitive (12 indices): targets 6, 3, 1, 0, 0 -> at most one level survives
+    assert shorter >= 5 and dropped >= 5            # lengths are data-dependent, and levels do get dropped
+    # the levels reference vertices of the primitive only, and every triangle of a level is non-degenerate and unique
+    for k, (p_, idx) in enumerate(prims):
+        for l in range(1, int(m["n_lods"][k])):
+            off, ln = int(m["index_offset"][k, l]), int(m["index_len"][k, l])
+            t = s["indices"][off : off + ln].reshape(-1, 3)
+            assert t.max() < len(p_) and np.all((t[:, 0] != t[:, 1]) & (t[:, 0] != t[:, 2]) & (t[:, 1] != t[:, 2]))
+            assert len({tuple(x) for x in t.tolist()}) == len(t)
 
 
 def test_extractor_rejects_malformed_input():
@@ -99,6 +162,26 @@ def test_extractor_rejects_malformed_input():
         assert r.returncode == 3 and "gltf json" in r.stderr
         r, _ = _extract(os.path.join(d, "missing.gltf"))
         assert r.returncode == 3
+
+
+def test_buffer_uris_cannot_leave_the_assets_directory():
+    """an untrusted .gltf must not make the extractor read arbitrary local files into its output blob."""
+    import json
+
+    with tempfile.TemporaryDirectory() as d:
+        g, blob, _ = gltf_fixture.build(embed=False)
+        os.mkdir(os.path.join(d, "a"))
+        open(os.path.join(d, "a", "buf.bin"), "wb").write(blob)
+        open(os.path.join(d, "secret.bin"), "wb").write(blob)
+        os.symlink(os.path.join(d, "secret.bin"), os.path.join(d, "a", "link.bin"))
+        src = os.path.join(d, "a", "s.gltf")
+        for uri, ok in (("buf.bin", True), ("./buf.bin", True), ("../secret.bin", False), (os.path.join(d, "secret.bin"), False),
+                        ("file:///etc/passwd", False), ("link.bin", False), ("sub/../buf.bin", False), ("..", False)):
+            g["buffers"][0]["uri"] = uri
+            json.dump(g, open(src, "w"))
+            r, _ = _extract(src)
+            assert (r.returncode == 0) == ok, (uri, r.returncode, r.stderr)
+            assert ok or r.returncode == 3
 
 
 @pytest.mark.gpu
