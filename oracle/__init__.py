@@ -9,6 +9,7 @@ from .oracle import (  # noqa: F401
     build,
     lib,
     run,
+    Runner,
     model_matrix,
     world_aabb,
     coarse_culled,

@@ -244,6 +244,46 @@ def run(pos_xyz, rot_ijkw, scale, mesh_id, meshes, planes, cam_pos, first_instan
     return res
 
 
+class Runner:
+    """The whole path with the outputs allocated and touched ONCE: `runner()` then only runs orc_run(_mt) into them, as
+    the reference's systems write into components that already exist. bench.py's cpu_baseline times this (round 2 timed
+    `run`, whose ~85 MB of fresh, untouched output arrays per pass flattered the GPU)."""
+
+    def __init__(self, pos_xyz, rot_ijkw, scale, mesh_id, meshes, planes, cam_pos, threads=None,
+                 want=("model", "visible_bitmap", "draw_cmds"), first_instance_base=0, first_index_base=0):
+        self.pos = _f32(pos_xyz).reshape(-1, 3)
+        n = self.n = self.pos.shape[0]
+        self.rot = _f32(rot_ijkw).reshape(-1, 4)
+        self.scale = _f32(scale).reshape(-1)
+        self.mesh_id = np.ascontiguousarray(mesh_id, dtype=np.uint32).reshape(-1)
+        self.meshes = np.ascontiguousarray(meshes, dtype=ORC_MESH_DTYPE).reshape(-1)
+        self.planes, self.cam = _f32(planes, (24,)), _f32(cam_pos, (3,))
+        self.threads = threads
+        self.out = {}
+        o = self.o = _Outputs()
+        if "model" in want:
+            self.out["model"] = np.zeros((n, 16), np.float32)
+            o.model = self.out["model"].ctypes.data
+        if "world_aabb" in want:
+            self.out["world_aabb"] = np.zeros((n, 6), np.float32)
+            o.world_aabb = self.out["world_aabb"].ctypes.data
+        if "visible_bitmap" in want:
+            self.out["visible_bitmap"] = np.zeros((n + 31) // 32, np.uint32)
+            o.visible_bitmap = self.out["visible_bitmap"].ctypes.data
+        if "draw_cmds" in want:
+            self.out["draw_cmds"] = np.zeros(max(n, 1), DRAW_CMD_DTYPE)
+            o.draw_cmds = self.out["draw_cmds"].ctypes.data
+        self.args = [C.c_uint32(n), _p(self.pos), _p(self.rot), _p(self.scale), _p(self.mesh_id), _p(self.meshes),
+                     C.c_uint32(len(self.meshes)), _p(self.planes), _p(self.cam), C.c_uint32(first_instance_base),
+                     C.c_uint32(first_index_base), C.byref(o)]
+
+    def __call__(self):
+        rc = lib().orc_run(*self.args) if self.threads is None else lib().orc_run_mt(*self.args, C.c_uint32(int(self.threads)))
+        if rc != 0:
+            raise ValueError("oracle: mesh id out of range or allocation failure")
+        return int(self.o.draw_count)
+
+
 def run_skinned(pos_xyz, rot_ijkw, scale, mesh_id, meshes, skeleton, poses, planes, cam_pos, first_instance_base=0,
                 first_index_base=0, threads=8, want=("model", "world_aabb", "visible_bitmap", "coarse_culled",
                                                      "draw_cmds", "palette")):

@@ -118,6 +118,19 @@ def library_path():
     return _SO
 
 
+def _declare_newer(lib, name, argtypes):
+    """Entry points added after ABI 2. The product library has them all (tests/test_abi.py); an older build loaded through
+    MIP_LIBRARY for a same-box A/B (tools/kbench.py against a previous round's kernel) may not — only then is one skipped."""
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        if os.environ.get("MIP_LIBRARY"):
+            return
+        raise
+    fn.argtypes = argtypes
+    fn.restype = C.c_int32
+
+
 def load_library():
     """Returns the ctypes handle. Raises ImportError if the HIP library has not been built —
     there is deliberately nothing to fall back to."""
@@ -163,8 +176,7 @@ def load_library():
     lib.mip_wait.restype = C.c_int32
     lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
     lib.mip_merge_draw_lists.restype = C.c_int32
-    lib.mip_merge_wire_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
-    lib.mip_merge_wire_lists.restype = C.c_int32
+    _declare_newer(lib, "mip_merge_wire_lists", [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32])
     lib.mip_light_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32]
     lib.mip_light_draw_lists.restype = C.c_int32
     lib.mip_set_skeleton.argtypes = [vp, vp, vp, vp, C.c_uint32]
@@ -187,16 +199,11 @@ def load_library():
     lib.mip_import_external_fd.restype = C.c_int32
     lib.mip_release_external.argtypes = [vp, vp]
     lib.mip_release_external.restype = C.c_int32
-    lib.mip_import_external_semaphore_fd.argtypes = [vp, C.c_int32, C.c_uint32, C.POINTER(vp)]
-    lib.mip_import_external_semaphore_fd.restype = C.c_int32
-    lib.mip_external_semaphore_on_device.argtypes = [vp, vp]
-    lib.mip_external_semaphore_on_device.restype = C.c_int32
-    lib.mip_wait_external.argtypes = [vp, vp, C.c_uint64]
-    lib.mip_wait_external.restype = C.c_int32
-    lib.mip_signal_external.argtypes = [vp, vp, C.c_uint64]
-    lib.mip_signal_external.restype = C.c_int32
-    lib.mip_release_external_semaphore.argtypes = [vp, vp]
-    lib.mip_release_external_semaphore.restype = C.c_int32
+    _declare_newer(lib, "mip_import_external_semaphore_fd", [vp, C.c_int32, C.c_uint32, C.POINTER(vp)])
+    _declare_newer(lib, "mip_external_semaphore_on_device", [vp, vp])
+    _declare_newer(lib, "mip_wait_external", [vp, vp, C.c_uint64])
+    _declare_newer(lib, "mip_signal_external", [vp, vp, C.c_uint64])
+    _declare_newer(lib, "mip_release_external_semaphore", [vp, vp])
     lib.mip_last_error.argtypes = [vp]
     lib.mip_last_error.restype = C.c_char_p
     lib.mip_get_timings.argtypes = [vp, C.POINTER(MipTimings)]

@@ -95,7 +95,6 @@ struct KernelArgs {
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
   uint32_t n_meshes;            // mesh-table entries
-  uint32_t wire;                // != 0: `cmds` receives the wire form of the list (MIP_OUT_WIRE; wire_copy_out below)
   // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
   // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
   // without re-recording: the host refreshes the ring with one copy per replay
@@ -645,9 +644,12 @@ constexpr uint32_t kAggArrivalShift = 24;
 //      matrix pieces while wave 0 spends that time on the prefix round trip and the copy-out.
 //      Shortest dependency chain per tile; best while every tile is in the launch's first and last
 //      generation of workgroups (100 k instances: 6.1 vs 6.9 us).
-template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder>
+// kWire: the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above). A template
+// parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
+template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder, bool kWire = false>
 __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
   static_assert(kOrder == 1 || kOrder == 3, "unknown order");
+  static_assert(!kWire || !kBoxOverride, "skinned frames do not emit the wire form");
   static_assert(kGeneral || !kBoxOverride, "a box override may be non-finite");
   __shared__ __attribute__((aligned(16))) float s_mat[kTile * 12];    // rows 0..2 of every matrix
   __shared__ uint32_t s_row3[kTile];                                     // NaN bits of row 3 + mesh id
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
       const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
       uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
       c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = first_instance_base + i;
-      c[5] = a.wire ? (mesh | (far_lod ? 0x80000000u : 0u)) : (far_lod ? md.z : md.y);
+      c[5] = kWire ? (mesh | (far_lod ? 0x80000000u : 0u)) : (far_lod ? md.z : md.y);
     }
     __syncthreads();
     MIP_STAMP(3);
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     MIP_STAMP(4);
     const uint32_t first_index_add = base_sum + first_index_base;
-    if (a.wire) {
+    if constexpr (kWire) {
       wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
       store_aabb();
       MIP_STAMP(5);
@@ -944,7 +946,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
     c[3] = md.x;                                              // vertexOffset, :66
     c[4] = first_instance_base + i;                         // firstInstance = draw_index, :64
-    c[5] = a.wire ? (mesh | (far_lod ? 0x80000000u : 0u))     // wire form: the record's second word
+    c[5] = kWire ? (mesh | (far_lod ? 0x80000000u : 0u))      // wire form: the record's second word
                   : (far_lod ? md.z : md.y);                  // push constant indexOffset, cull_pipeline.rs:552
   }
   __syncthreads();  // commands, staged matrices and visibility words of every wave are in LDS
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   // ---- coalesced copy-out of the tile's commands ----
   const uint32_t first_index_add = base_sum + first_index_base;
-  if (a.wire) {
+  if constexpr (kWire) {
     wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
     store_aabb();
     MIP_STAMP(5);

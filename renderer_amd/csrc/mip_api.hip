@@ -298,15 +298,15 @@ const RcclApi* rccl() {
 // whenever the census says every resident instance passes the finite test (and no per-instance
 // box override, which may be non-finite, is in play).
 using FrameKernel = void (*)(const mip::KernelArgs);
-template <bool kBox, bool kGeneral>
+template <bool kBox, bool kGeneral, bool kWire>
 FrameKernel pick_order(bool ticketed, int order) {
   if (ticketed)
-    return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1>
-                      : (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 3>;
-  return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1>
-                    : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 3>;
+    return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1, kWire>
+                      : (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 3, kWire>;
+  return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1, kWire>
+                    : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 3, kWire>;
 }
-FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool tlas, uint32_t* grid) {
+FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool wire, uint32_t* grid) {
   const uint32_t n_tiles = tiles_for(ctx->n);
   *grid = n_tiles;
   // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of
@@ -316,10 +316,10 @@ FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool t
   // (2 M: 34.1 vs 35.7; 4 M: 64.4 vs 68; 10 M: 181 vs 232 us; 1 M: equal within the run-to-run spread).
   int order = n_tiles <= (uint32_t)ctx->cu_count * 14u ? 3 : 1;
   if (ctx->force_order) order = ctx->force_order;
-  (void)tlas;
-  if (box_override) return pick_order<true, true>(ctx->ordered_tiles, order);
-  if (ctx->nonfinite_instances != 0 || ctx->force_general) return pick_order<false, true>(ctx->ordered_tiles, order);
-  return pick_order<false, false>(ctx->ordered_tiles, order);
+  if (box_override) return pick_order<true, true, false>(ctx->ordered_tiles, order);  // (validate_run refuses MIP_OUT_WIRE for skinned frames)
+  const bool general = ctx->nonfinite_instances != 0 || ctx->force_general;
+  if (wire) return general ? pick_order<false, true, true>(ctx->ordered_tiles, order) : pick_order<false, false, true>(ctx->ordered_tiles, order);
+  return general ? pick_order<false, true, false>(ctx->ordered_tiles, order) : pick_order<false, false, false>(ctx->ordered_tiles, order);
 }
 
 // Number of instances of [first, first + count) of the resident columns that fail the finite test, and (bad_ids != null)
@@ -373,7 +373,6 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
-  a.wire = (device_out && (out->flags & MIP_OUT_WIRE)) ? 1u : 0u;
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
@@ -830,6 +829,7 @@ int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const voi
 
 static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, bool skinned, void* palette) {
   if (int32_t rc = validate_run(ctx, frame, out)) return rc;
+  if (skinned && (out->flags & MIP_OUT_WIRE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE is not available for skinned frames");
   const bool device_out = (out->flags & MIP_OUT_DEVICE) != 0;
   const bool async = device_out && (out->flags & MIP_OUT_ASYNC) != 0;
   const bool triangles = out->culled_index_buffer != nullptr;
@@ -905,7 +905,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       void* params[1] = {&a};
       if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
       uint32_t grid = 0;
-      const FrameKernel kernel = select_frame_kernel(ctx, skinned, a.tlas_instances != nullptr, &grid);
+      const FrameKernel kernel = select_frame_kernel(ctx, skinned, device_out && (out->flags & MIP_OUT_WIRE) != 0, &grid);
       MIP_HIP(ctx, hipLaunchKernel((const void*)kernel, dim3(grid), dim3(mip::kTile), params, ctx->lds_pad, stream));
     }
     if (triangles) {
@@ -1128,7 +1128,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           void* params[1] = {&a};
           hipKernelNodeParams kp{};
           uint32_t grid = 0;
-          kp.func = (void*)select_frame_kernel(ctx, false, a.tlas_instances != nullptr, &grid);
+          kp.func = (void*)select_frame_kernel(ctx, false, (out->flags & MIP_OUT_WIRE) != 0, &grid);
           kp.gridDim = dim3(grid);
           kp.blockDim = dim3(mip::kTile);
           kp.sharedMemBytes = ctx->lds_pad;
