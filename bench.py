@@ -469,11 +469,8 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
             "bound": "valu", "kernel": list(doc["kernel_ns_under_pmc"].keys())[0], "achieved": valu / (kern_ns * 1e-9),
             "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instructions/s", "frac": valu / (kern_ns * 1e-9) / VALU_PEAK_WAVE_INSTR_PER_S,
             "valu_wave_instructions_per_launch": valu, "kernel_ms": kern_ns * 1e-6, "source": src,
-            "simd_valu_busy_fraction": (doc["counters_per_launch"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * doc["counters_per_launch"]["GRBM_GUI_ACTIVE"] / 8.0)
-                                        if doc["counters_per_launch"].get("SQ_ACTIVE_INST_VALU") and doc["counters_per_launch"].get("GRBM_GUI_ACTIVE") else None),
             "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; peak = one wave64 f32 VALU instruction per "
-                    "4 cycles per SIMD (the kernel has no packed instructions: its translation unit is built without the SLP vectoriser). "
-                    "simd_valu_busy_fraction = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles): the same thing measured by the busy counter",
+                    "4 cycles per SIMD (the kernel has no packed instructions: its translation unit is built without the SLP vectoriser)",
         }
     if with_cpu:
         import oracle
