@@ -40,7 +40,7 @@ def test_cpu_leg_thread_count_is_bounded(monkeypatch):
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert key in line, key
