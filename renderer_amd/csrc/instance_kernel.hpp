@@ -754,6 +754,15 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   }
 
   MIP_STAMP(1);
+  // The emitting lanes need their mesh's vertex_offset. Its gather used to sit behind the keep decision, i.e. one L2
+  // round trip inside the tile's dependency chain (barrier -> gather -> assembly -> barrier -> copy-out); issued here
+  // it returns under the plane tests. (The two source index offsets of the per-triangle stage stay a late, conditional
+  // 16-byte gather: only those frames read them.)
+  // Only in the commands-first order (small launches, latency-bound: 100 k 5.83 -> 5.52 us, 200 k 7.04 -> 6.82): a gather
+  // by every lane instead of the emitting ones costs the stores-first order 0.5 us at 1 M (profiles/r03_vertex_offset_early_ab.txt).
+  int32_t vertex_offset_of_mesh = 0;
+  if constexpr (kOrder == 3)
+    if (want_cmds) vertex_offset_of_mesh = a.mesh_draw[mesh].vertex_offset;
   // ---- frustum test, LOD, command length ----
   const bool culled = coarse_culled(inst, planes);
   const bool visible = active && !culled;
@@ -881,10 +890,11 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     __syncthreads();  // waves 1-3 have read their staged matrices: their area is free for the commands
     if (keep) {
-      const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
       uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
-      c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = md.x; c[4] = first_instance_base + i;
-      c[5] = kWire ? (mesh | (far_lod ? 0x80000000u : 0u)) : (far_lod ? md.z : md.y);
+      vertex_offset_of_mesh = a.mesh_draw[mesh].vertex_offset;  // stores-first order: gathered by the emitting lanes only
+      c[0] = len; c[1] = 1u; c[2] = wave_off_sum + (incl_sum - len_vis); c[3] = (uint32_t)vertex_offset_of_mesh; c[4] = first_instance_base + i;
+      if constexpr (kWire) c[5] = mesh | (far_lod ? 0x80000000u : 0u);
+      else if (a.src_index_offset) c[5] = far_lod ? a.mesh_draw[mesh].src_offset1 : a.mesh_draw[mesh].src_offset0;
     }
     __syncthreads();
     MIP_STAMP(3);
@@ -939,15 +949,15 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   // ---- tile-local command assembly in LDS (firstIndex still relative to the tile) ----
   if (keep) {
-    const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
     uint32_t* c = &s_cmd[(wave_off_count + rank_in_wave) * kCmdLdsWords];
     c[0] = len;                                               // indexCount
     c[1] = 1u;                                                // instanceCount, generate_work.comp:63
     c[2] = wave_off_sum + (incl_sum - len_vis);               // firstIndex (tile-relative)
-    c[3] = md.x;                                              // vertexOffset, :66
+    c[3] = (uint32_t)vertex_offset_of_mesh;                   // vertexOffset, :66
     c[4] = first_instance_base + i;                         // firstInstance = draw_index, :64
-    c[5] = kWire ? (mesh | (far_lod ? 0x80000000u : 0u))      // wire form: the record's second word
-                  : (far_lod ? md.z : md.y);                  // push constant indexOffset, cull_pipeline.rs:552
+    if constexpr (kWire) c[5] = mesh | (far_lod ? 0x80000000u : 0u);  // wire form: the record's second word
+    else if (a.src_index_offset)                              // push constant indexOffset, cull_pipeline.rs:552 (per-triangle stage only)
+      c[5] = far_lod ? a.mesh_draw[mesh].src_offset1 : a.mesh_draw[mesh].src_offset0;
   }
   __syncthreads();  // commands, staged matrices and visibility words of every wave are in LDS
   MIP_STAMP(3);
