@@ -95,6 +95,33 @@ def test_wire_list_is_the_command_list(ra, oracle_mod, n):
                          culled_index_buffer=body.data_ptr(), culled_index_capacity=4)
 
 
+def test_wire_form_in_ordered_tiles_mode_and_with_non_finite_instances(ra, oracle_mod, monkeypatch):
+    """The wire form is a template parameter of the frame kernel: the ticketed (ordered tiles) and the general (literal
+    arithmetic) instantiations carry it too."""
+    import torch
+
+    from cpu_pipeline import decode_wire
+    from renderer_amd.pipeline import make_frame, wire_body_bytes
+
+    dev = torch.device("cuda", 0)
+    s = ra.scene.make_scene(3, n=90_001)
+    s["pos"][17] = np.nan
+    s["scale"][4000] = np.inf
+    want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+    for ordered in (False, True):
+        with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, ordered_tiles=ordered) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            body = torch.zeros(wire_body_bytes(s["n"]) // 4, dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                p.run_device(make_frame(s["planes"], s["cam_pos"]), draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), wire=True)
+            count = int(scal[0].item())
+            assert count == want["draw_count"] and p.timings()["general_launches"] == 2  # the NaN / inf instances select the literal tier
+            assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), ordered
+
+
 @pytest.mark.parametrize("n_global,world", [(10, 3), (70_001, 3), (1_000_000, 8)])
 def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
     """Shards of one scene run into wire chunks and into 20-byte chunks laid out as an all-gather would; both merges
