@@ -92,44 +92,67 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
   __shared__ uint32_t s_wave_total[4];
   __shared__ uint32_t s_out[kWireBlockCmds * kCmdWords];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (tid == 0) {
-    uint32_t c = 0, s = 0, nb = 0;
+  // chunk tables: lane k of wave 0 reads header k (one round trip for all <= 64 chunks, not one per chunk), three wave scans
+  if (wave == 0) {
     const uint32_t fits = (uint32_t)((a.stride - 32u) / (kWireBlockWords * 4u)) * kWireBlockCmds;
     const uint32_t capacity = a.capacity < fits ? a.capacity : fits;
-    for (uint32_t k = 0; k < a.n_chunks; ++k) {
-      const uint32_t* h = reinterpret_cast<const uint32_t*>(a.chunks + k * a.stride);
-      uint32_t count = h[0];
-      if (count > capacity) {  // the shard emitted more than the exchanged chunk holds
-        count = capacity;
-        if (blockIdx.x == 0) raise_error(a.error_flag, kErrChunkOverflow);
-      }
-      s_count_base[k] = c;
-      s_index_base[k] = s;
-      s_block_base[k] = nb;
-      c += count;
-      s += h[1];
-      nb += (count + kWireBlockCmds - 1u) / kWireBlockCmds;
+    uint32_t count = 0, total = 0;
+    if (lane < a.n_chunks) {
+      const uint2 h = *reinterpret_cast<const uint2*>(a.chunks + lane * a.stride);
+      count = h.x;
+      total = h.y;
     }
-    s_count_base[a.n_chunks] = c;
-    s_index_base[a.n_chunks] = s;
-    s_block_base[a.n_chunks] = nb;
-    if (blockIdx.x == 0) {
-      a.out_count[0] = c;
-      a.out_count[1] = s;
+    if (__any(count > capacity) && blockIdx.x == 0 && lane == 0) raise_error(a.error_flag, kErrChunkOverflow);  // a shard emitted more than the exchanged chunk holds
+    count = count > capacity ? capacity : count;
+    const uint32_t blocks = (count + kWireBlockCmds - 1u) / kWireBlockCmds;
+    const uint32_t c_incl = wave_inclusive_scan(count), s_incl = wave_inclusive_scan(total), b_incl = wave_inclusive_scan(blocks);
+    if (lane < a.n_chunks) {
+      s_count_base[lane] = c_incl - count;
+      s_index_base[lane] = s_incl - total;
+      s_block_base[lane] = b_incl - blocks;
+    }
+    if (lane == 63u) {  // lanes past the last chunk contributed zeros: lane 63 holds the totals
+      s_count_base[a.n_chunks] = c_incl;
+      s_index_base[a.n_chunks] = s_incl;
+      s_block_base[a.n_chunks] = b_incl;
+      if (blockIdx.x == 0) {
+        a.out_count[0] = c_incl;
+        a.out_count[1] = s_incl;
+      }
     }
   }
   __syncthreads();
   const uint32_t total_blocks = s_block_base[a.n_chunks];
+  // where block `blk` of the merged list lives: its chunk, its number inside the chunk, its live records, its words
   uint32_t chunk = 0;
-  for (uint32_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+  auto locate = [&](uint32_t blk, uint32_t& b, uint32_t& in_block, const uint32_t*& body) {
     while (blk >= s_block_base[chunk + 1]) ++chunk;  // blk only grows
-    const uint32_t b = blk - s_block_base[chunk];
+    b = blk - s_block_base[chunk];
     const uint32_t chunk_count = s_count_base[chunk + 1] - s_count_base[chunk];
-    const uint32_t in_block = chunk_count - b * kWireBlockCmds < kWireBlockCmds ? chunk_count - b * kWireBlockCmds : kWireBlockCmds;
-    const uint32_t* body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kWireBlockWords;
+    in_block = chunk_count - b * kWireBlockCmds < kWireBlockCmds ? chunk_count - b * kWireBlockCmds : kWireBlockCmds;
+    body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kWireBlockWords;
+  };
+  // software pipeline: the records (and the block header) of a workgroup's NEXT block are in flight while it expands this one
+  uint32_t nb = 0, n_in_block = 0, n_chunk = 0, n_first_index = 0;
+  const uint32_t* n_body = nullptr;
+  uint2 n_rec = make_uint2(0u, 0u);
+  if (blockIdx.x < total_blocks) {
+    locate(blockIdx.x, nb, n_in_block, n_body);
+    n_chunk = chunk;
+    if (tid < n_in_block) n_rec = *reinterpret_cast<const uint2*>(n_body + kWireBlockHeaderWords + 2u * tid);
+    n_first_index = n_body[0];
+  }
+  for (uint32_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+    const uint32_t b = nb, in_block = n_in_block, this_chunk = n_chunk, first_index = n_first_index;
+    const uint2 rec = n_rec;
     const bool valid = tid < in_block;
-    uint2 rec = make_uint2(0u, 0u);
-    if (valid) rec = *reinterpret_cast<const uint2*>(body + kWireBlockHeaderWords + 2u * tid);
+    if (blk + gridDim.x < total_blocks) {
+      locate(blk + gridDim.x, nb, n_in_block, n_body);
+      n_chunk = chunk;
+      n_rec = make_uint2(0u, 0u);
+      if (tid < n_in_block) n_rec = *reinterpret_cast<const uint2*>(n_body + kWireBlockHeaderWords + 2u * tid);
+      n_first_index = n_body[0];
+    }
     uint32_t mesh = rec.y & 0x7fffffffu;
     if (mesh >= a.n_meshes) {  // never follow a corrupt record out of the table
       if (valid) raise_error(a.error_flag, kErrWireRecord);
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
     const uint32_t incl = wave_inclusive_scan(len);
     if (lane == 63u) s_wave_total[wave] = incl;
     __syncthreads();  // wave totals in; also: the previous block's copy-out has read s_out
-    uint32_t before = body[0] + s_index_base[chunk] + (incl - len);
+    uint32_t before = first_index + s_index_base[this_chunk] + (incl - len);
 #pragma unroll
     for (uint32_t w = 0; w < 3; ++w)
       if (w < wave) before += s_wave_total[w];
@@ -153,7 +176,7 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
       c[0] = len; c[1] = 1u; c[2] = before; c[3] = (uint32_t)vertex_offset; c[4] = rec.x;
     }
     __syncthreads();
-    uint32_t* out = a.out_cmds + ((size_t)s_count_base[chunk] + (size_t)b * kWireBlockCmds) * kCmdWords;
+    uint32_t* out = a.out_cmds + ((size_t)s_count_base[this_chunk] + (size_t)b * kWireBlockCmds) * kCmdWords;
     for (uint32_t j = tid; j < in_block * kCmdWords; j += 256u) out[j] = s_out[j];
   }
 }

@@ -1533,7 +1533,8 @@ static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t 
   a.n_meshes = ctx->m;
   // one workgroup expands one block of 256 records at a time; sized for the blocks the chunks can hold
   const uint64_t max_blocks = ((uint64_t)chunk_capacity + mip::kWireBlockCmds - 1) / mip::kWireBlockCmds * n_chunks;
-  uint32_t blocks = max_blocks > 256u * 8u ? 256u * 8u : (uint32_t)max_blocks;
+  const uint32_t grid_cap = std::getenv("MIP_TUNE_MERGE_GRID") ? (uint32_t)std::atoi(std::getenv("MIP_TUNE_MERGE_GRID")) : 256u * 8u;
+  uint32_t blocks = max_blocks > grid_cap ? grid_cap : (uint32_t)max_blocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(mip::mip_merge_wire_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
   MIP_HIP(ctx, hipGetLastError());

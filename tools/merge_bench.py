@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times mip_merge_draw_lists for R chunks shaped like the 10 M / 8-rank exchange."""
+"""Times the shard merge for R chunks shaped like the 10 M / 8-rank exchange: mip_merge_wire_lists (default, the wire form
+the ranks exchange) or mip_merge_draw_lists (`merge_bench.py R cmds`, the 20-byte form of round 2)."""
 import os
 import sys
 
@@ -13,6 +14,7 @@ from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
 from renderer_amd.sharded import chunk_stride_bytes
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+WIRE = not (len(sys.argv) > 2 and sys.argv[2] == "cmds")
 n = 1_250_000
 s = scene.make_scene(4, n=n)
 dev = torch.device("cuda", 0)
@@ -20,23 +22,25 @@ p = renderer_amd.InstancePipeline(n, len(s["meshes"]), timing=True)
 p.set_mesh_table(s["meshes"])
 p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
 cap = 360_000
-stride = chunk_stride_bytes(cap)
+stride = chunk_stride_bytes(cap, wire=WIRE)
 recv = torch.zeros(R * stride // 4, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 for k in range(R):
     base = recv.data_ptr() + k * stride
     p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=k * n), draw_cmds=base + SHARD_HEADER_BYTES,
-                 draw_count=base, draw_index_total=base + 4)
+                 draw_count=base, draw_index_total=base + 4, wire=WIRE)
 count = int(recv[0].item())
 merged = torch.zeros((R * cap, 5), dtype=torch.int32, device=dev)
 oc = torch.zeros(2, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
+merge = p.merge_wire_lists if WIRE else p.merge_draw_lists
 for _ in range(5):
-    p.merge_draw_lists(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr())
+    merge(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap)
 p.reset_timings()
 for _ in range(20):
-    p.merge_draw_lists(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr())
+    merge(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap)
 t = p.timings()
 ms = t["total_merge_ms"] / t["merges"]
-print(f"{R} chunks x {count} cmds ({count*20/1e6:.1f} MB each): merge {ms*1e3:.1f} us, {R*count*40/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
+per_cmd = (8.0625 + 20) if WIRE else 40
+print(f"{'wire' if WIRE else '20-byte'} form, {R} chunks x {count} cmds: merge {ms*1e3:.1f} us, {R*count*per_cmd/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
 p.close()
