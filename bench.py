@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs reported under 'extra'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sharded-extras", action="store_true",
+                    help="N>1 only: also time the exchange with two frames in flight (two contexts on two streams). Off by default: a "
+                         "secondary leg that fails on ONE rank leaves the others inside a collective, and the N>1 headline is worth more "
+                         "than the extra row")
     ap.add_argument("--native-rccl-leg", action="store_true",
                     help="N>1 only: also time mip_run_sharded (RCCL opened by the library itself); it creates a second "
                          "communicator beside torch's")
@@ -624,7 +628,7 @@ def main():
 
     if not args.no_extra and not distributed and args.config is None and args.instances is None and not args.all_visible:
         secondary_single(args, torch, renderer_amd, scene, make_frame, device, local_rank, stream, extra)
-    if not args.no_extra and distributed and args.config is None and args.instances is None:
+    if not args.no_extra and distributed and args.config is None and args.instances is None and (args.sharded_extras or args.native_rccl_leg or world == 1):
         secondary_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, local_rank, rank, world, stream, extra)
 
     if extra:
