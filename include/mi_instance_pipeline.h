@@ -54,11 +54,15 @@ extern "C" {
                                      * GPU: such a frame ends with MIP_ERR_TIMEOUT after a bounded wait — 0.5 s and
                                      * 2^18 polls — its outputs are invalid, and the context switches itself to this
                                      * mode for every later frame). With this flag the cross-tile prefix cannot stall
-                                     * whatever order workgroups start in, other tenants included. Cost: one returning
-                                     * atomic on ONE address per workgroup, ~11 ns each and serialised: 10.6 instead of
-                                     * 6.4 us at 100 k instances, 55 instead of 21 us at 1 M (MI355X). Set it when
-                                     * the GPU is shared with other compute that waits on the device. mip_run_views
-                                     * runs one frame per view in this mode. */
+                                     * whatever order workgroups start in, other tenants included. Small launches (up to
+                                     * 512 tiles = 131 072 instances) take their tile numbers from a counter — one
+                                     * returning atomic on ONE address per workgroup, ~11 ns each and serialised: 9.7
+                                     * instead of 5.6 us at 100 k instances; larger ones run as THREE launches none of
+                                     * which waits for another workgroup (per-tile aggregates, their scan, the frame
+                                     * kernel reading its prefix: the instance data is read twice): 31.7 instead of
+                                     * 18.6 us at 1 M instances, 278 instead of 179 at 10 M (tickets: 56 / 463;
+                                     * DESIGN.md section 14.8). Set it when the GPU is shared with other compute that waits
+                                     * on the device. mip_run_views runs one frame per view in this mode. */
 
 /* ---- MipOutputs.flags ---- */
 #define MIP_OUT_HOST 0x0u   /* output pointers are host memory (copied back, synchronous) */
@@ -184,6 +188,7 @@ typedef struct MipTimings {
   uint64_t graph_records;     /* times it had to record a new set of graphs */
   uint64_t sharded_retries;   /* sharded frames whose tightened chunk overflowed and were re-gathered at full capacity */
   uint64_t sharded_bytes_sent; /* bytes this rank contributed to the last sharded frame's all-gather */
+  uint64_t three_pass_frames;  /* ordered-tiles frames that ran as three wait-free launches (large launches) instead of one ticketed one */
   uint64_t general_launches;  /* frames launched with the kernel that carries the literal path for non-finite
                                  inputs (some resident instance failed the upload-time finite test, or a skinned frame) */
 } MipTimings;

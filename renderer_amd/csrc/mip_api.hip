@@ -52,6 +52,8 @@ struct MipContext {
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
     bool parts_dirty = false;                //                     a parts launch timed out: clear the granules before the next one
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
+    uint2* d_tile_agg = nullptr;             // ordered tiles, large launches (three-pass mode): per tile {count, sum}, then their exclusive prefixes
+    uint2* d_tile_prefix = nullptr;
     // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
     // refreshed before every replay from one of two pinned staging halves
     uint32_t* d_frame_ring = nullptr;
@@ -117,6 +119,9 @@ struct MipContext {
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
+  uint32_t ordered_three_pass_min_tiles = 512;   // ordered tiles: launches of more tiles than this take three wait-free launches
+                                                  // instead of one ticket per tile (MIP_TUNE_THREE_PASS_MIN_TILES; measured crossover
+                                                  // in profiles/r03_ordered_tiles_three_pass.txt)
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
                                    // measured (DamagedHelmet entry, frame time parts / workgroup-per-command): 30 instances 14 / 24 us,
@@ -513,6 +518,8 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_tmp_blocks);
     (void)hipFree(sl.d_part_status);
     (void)hipFree(sl.d_skin_box);
+    (void)hipFree(sl.d_tile_agg);
+    (void)hipFree(sl.d_tile_prefix);
     (void)hipFree(sl.d_frame_ring);
     if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
     for (auto& e : sl.stage_free)
@@ -608,6 +615,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDERED_TILES")) ctx->ordered_tiles = std::atoi(env) != 0;
+    if (const char* env = std::getenv("MIP_TUNE_THREE_PASS_MIN_TILES")) ctx->ordered_three_pass_min_tiles = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDER")) {
       const int v = std::atoi(env);
       if (v == 1 || v == 3) ctx->force_order = v;
@@ -900,6 +908,30 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       const uint32_t per_block = 4u * (64u / ctx->n_joints);
       hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(mip::kSkinBlock), 0, stream, k);
       MIP_HIP(ctx, hipGetLastError());
+    }
+    if (a.cmds && ctx->ordered_tiles && a.n_tiles > ctx->ordered_three_pass_min_tiles) {
+      // ordered tiles, large launch: two wait-free launches produce every tile's prefix, the frame kernel then reads it
+      // (instance_kernel.hpp, "the prefix without any wait")
+      const size_t tiles_cap = tiles_for(ctx->max_instances ? ctx->max_instances : 1);
+      if (!sl.d_tile_agg) MIP_HIP(ctx, hipMalloc(&sl.d_tile_agg, tiles_cap * sizeof(uint2)));
+      if (!sl.d_tile_prefix) MIP_HIP(ctx, hipMalloc(&sl.d_tile_prefix, tiles_cap * sizeof(uint2)));
+      mip::TileAggregateArgs ta{};
+      ta.k = a;
+      ta.tile_agg = sl.d_tile_agg;
+      const bool general = skinned || ctx->nonfinite_instances != 0 || ctx->force_general;
+      if (skinned) hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<true, true>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
+      else if (general) hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<false, true>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
+      else hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<false, false>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
+      mip::TileScanArgs ts{};
+      ts.tile_agg = sl.d_tile_agg;
+      ts.tile_prefix = sl.d_tile_prefix;
+      ts.n_tiles = a.n_tiles;
+      ts.draw_count = a.draw_count;
+      ts.index_total = a.index_total;
+      hipLaunchKernelGGL(mip::mip_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
+      MIP_HIP(ctx, hipGetLastError());
+      a.tile_prefix = sl.d_tile_prefix;
+      ctx->timings.three_pass_frames += 1;
     }
     {
       void* params[1] = {&a};

@@ -559,3 +559,73 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         open(os.path.join(out, "external_semaphore_notes.txt"), "w").write("\n".join(notes) + "\n")
+
+
+@pytest.mark.parametrize("min_tiles", ["0", "default"])
+def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
+    """MIP_CFG_ORDERED_TILES on large launches: three launches none of which waits for another workgroup (per-tile
+    aggregates, their scan, the frame kernel reading its prefix) instead of one ticket per tile. Same bytes as the default
+    kernel: plain frames at sizes either side of the switch, non-finite instances (literal tier in BOTH the aggregate pass
+    and the frame kernel), the wire form, bases, host outputs, the per-triangle stage (its scratch list and count), a
+    skinned frame (box override) and culled views. min_tiles=0 forces the mode onto every launch."""
+    import torch
+
+    from cpu_pipeline import decode_wire
+    from renderer_amd.pipeline import make_frame, wire_body_bytes
+
+    if min_tiles != "default":
+        monkeypatch.setenv("MIP_TUNE_THREE_PASS_MIN_TILES", min_tiles)
+    dev = torch.device("cuda", 0)
+    for n in ((1, 255, 4_097, 70_001) if min_tiles == "0" else (131_072, 131_073, 1_200_003)):
+        s = ra.scene.make_scene(3, n=n)
+        if n > 300:
+            s["pos"][17] = np.nan
+            s["scale"][200] = np.inf
+        want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=8,
+                              first_instance_base=11, first_index_base=5)
+        with ra.InstancePipeline(max_instances=n, max_meshes=64, ordered_tiles=True) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            for rep in range(2):
+                got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5)
+                from helpers import assert_parity
+                assert_parity(got, want, f"three-pass n={n} rep={rep}")
+            expect_three = 2 if (min_tiles == "0" or (n + 255) // 256 > 512) else 0
+            assert p.timings()["three_pass_frames"] == expect_three, (n, p.timings()["three_pass_frames"])
+            body = torch.zeros(wire_body_bytes(n) // 4, dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5), draw_cmds=body.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire=True)
+            count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
+            assert count == want["draw_count"] and total == want["draw_index_total"]
+            assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), n
+    if min_tiles != "0":
+        return
+    # the per-triangle stage behind a three-pass frame
+    from test_gpu_triangles import _oracle, _run_gpu
+    monkeypatch.setenv("MIP_TUNE_ORDERED_TILES", "1")
+    s = ra.scene.make_scene(3, n=3000)
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    pv = ra.scene.default_pv()
+    r0 = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
+    capacity = r0["draw_index_total"] + 3
+    r, want_cmds, want_out = _oracle(oracle_mod, s, vertices, indices, pv, capacity)
+    got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, frames=2)
+    assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes() and np.array_equal(got_out, want_out)
+    # a skinned frame (per-instance box override in both passes)
+    sk = ra.scene.make_skinned_scene(5000)
+    ws = oracle_mod.run_skinned(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"], sk["meshes"], sk["skeleton"], sk["poses"], sk["planes"], sk["cam_pos"])
+    with ra.InstancePipeline(max_instances=5000, max_meshes=1, ordered_tiles=True) as p:
+        p.set_mesh_table(sk["meshes"])
+        p.set_instances(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"])
+        p.set_skeleton(sk["skeleton"]["parent"], sk["skeleton"]["inverse_bind"], sk["skeleton"]["joint_box"])
+        p.set_poses(sk["poses"])
+        cmds = torch.zeros((5000, 5), dtype=torch.int32, device=dev)
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            p.run_skinned(make_frame(sk["planes"], sk["cam_pos"]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
+        count = int(scal[0].item())
+        assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
+        assert p.timings()["three_pass_frames"] == 2
