@@ -21,7 +21,6 @@ def test_oracle_vs_numpy_restatement_random_scenes(oracle_mod, seed):
     assert np.array_equal(c["firstInstance"], b["cmds"]["firstInstance"]) and np.array_equal(c["vertexOffset"], b["cmds"]["vertexOffset"])
 
 
-@pytest.mark.gpu
 def _check_wire_form(ra, p, s, want, what):
     """The same frame emitted in the wire form (MIP_OUT_WIRE) and expanded against the mesh table (the numpy statement of what
     mip_merge_wire_lists does, tests/cpu_pipeline.py) must give the oracle's command bytes — special values, empty LODs, random
@@ -50,6 +49,7 @@ def _check_wire_form(ra, p, s, want, what):
     assert int(scal[0].item()) == count and merged[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
 
 
+@pytest.mark.gpu
 def test_gpu_vs_oracle_random_scenes(oracle_mod):
     import renderer_amd as ra
 
