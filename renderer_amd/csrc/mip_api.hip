@@ -1225,7 +1225,9 @@ int32_t mip_run_many(MipContext* ctx, const MipFrame* frames, uint32_t n_frames,
   }
   uint32_t done = 0;
   const uint32_t F = (uint32_t)ctx->slots.size();
-  if (plain && ctx->graph_round && ctx->n && !(ctx->cfg_flags & MIP_CFG_TIMING)) {
+  // (ordered tiles on a large launch is three launches per frame, set up by run_frame: not recorded)
+  const bool three_pass = ctx->ordered_tiles && tiles_for(ctx->n) > ctx->ordered_three_pass_min_tiles;
+  if (plain && !three_pass && ctx->graph_round && ctx->n && !(ctx->cfg_flags & MIP_CFG_TIMING)) {
     // a round = the smallest run after which slot and output rotation repeat, with an even
     // number of frames per slot, scaled up to about graph_round frames
     uint32_t a = F, b = n_outputs;

@@ -601,6 +601,25 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
             assert count == want["draw_count"] and total == want["draw_index_total"]
             assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), n
     if min_tiles != "0":
+        # frames issued from compiled code (mip_run_many) take the same path: large ordered launches are not recorded as graphs
+        s = ra.scene.make_scene(3, n=300_000)
+        want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
+        with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2, ordered_tiles=True) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            sets = []
+            for _ in range(2):
+                cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
+                scal = torch.zeros(8, dtype=torch.int32, device=dev)
+                sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
+            torch.cuda.synchronize()
+            p.run_many(make_frame(s["planes"], s["cam_pos"]), [x[2] for x in sets], 130)
+            p.wait()
+            t = p.timings()
+            assert t["graph_frames"] == 0 and t["three_pass_frames"] == 130
+            for cmds, scal, _ in sets:
+                count = int(scal[0].item())
+                assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
         return
     # the per-triangle stage behind a three-pass frame
     from test_gpu_triangles import _oracle, _run_gpu
