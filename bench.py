@@ -140,8 +140,11 @@ def stats(ms):
 
 
 def kernel_source_sha():
+    """Hash of the source that defines the frame kernel's device code (instance_kernel.hpp): a PMC summary is this kernel's
+    traffic only if it was collected from the same source. (Round 2 hashed mip_api.hip too, so every host-side edit made the
+    committed summary "stale" although the kernel had not changed.)"""
     h = hashlib.sha256()
-    for f in ("instance_kernel.hpp", "mip_api.hip"):
+    for f in ("instance_kernel.hpp",):
         h.update(open(os.path.join(ROOT, "renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

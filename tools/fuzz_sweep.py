@@ -49,10 +49,32 @@ for seed in range(first, first + seeds):
     fib, fxb = s["first_instance_base"], s["first_index_base"]
     want = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"],
                       first_instance_base=fib, first_index_base=fxb, threads=8)
-    with ra.InstancePipeline(max_instances=max(n, 1), max_meshes=64, frames_in_flight=int(rng.integers(1, 4))) as p:
+    # round 3: a quarter of the seeds in ordered-tiles mode, half of those with the three wait-free launches forced onto every size
+    ordered = seed % 4 == 1
+    os.environ.pop("MIP_TUNE_THREE_PASS_MIN_TILES", None)
+    if ordered and seed % 8 == 1:
+        os.environ["MIP_TUNE_THREE_PASS_MIN_TILES"] = "0"
+    with ra.InstancePipeline(max_instances=max(n, 1), max_meshes=64, frames_in_flight=int(rng.integers(1, 4)), ordered_tiles=ordered) as p:
         p.set_mesh_table(s["meshes"])
         p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
         got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb)
+        if n:  # the same frame in the wire form, expanded by the merge kernel (one chunk) and by the numpy statement
+            from cpu_pipeline import decode_wire
+            from renderer_amd.pipeline import SHARD_HEADER_BYTES
+            from renderer_amd.sharded import chunk_stride_bytes
+            stride = chunk_stride_bytes(n, wire=True)
+            chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
+            merged = torch.full((n, 5), -1, dtype=torch.int32, device=dev)
+            mc = torch.zeros(2, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb), draw_cmds=chunk.data_ptr() + SHARD_HEADER_BYTES,
+                         draw_count=chunk.data_ptr(), draw_index_total=chunk.data_ptr() + 4, wire=True)
+            host = chunk.cpu().numpy().view(np.uint32)
+            p.merge_wire_lists(chunk.data_ptr(), 1, stride, merged.data_ptr(), mc.data_ptr(), chunk_capacity=n)
+            if not (int(host[0]) == want["draw_count"] and int(host[1]) == want["draw_index_total"]
+                    and decode_wire(host[SHARD_HEADER_BYTES // 4:], int(host[0]), s["meshes"]).tobytes() == want["draw_cmds"].tobytes()
+                    and merged[: int(host[0])].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()):
+                fail(seed, f"wire form n={n} ordered={ordered}")
         if not (np.array_equal(got["visible_bitmap"], want["visible_bitmap"]) and got["draw_count"] == want["draw_count"]
                 and got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes() and got["draw_index_total"] == want["draw_index_total"]
                 and same(got["model"], want["model"]) and same(got["world_aabb"], want["world_aabb"])):
@@ -130,7 +152,7 @@ for seed in range(first, first + seeds):
         t = ra.scene.make_scene(cfg, n=nt, all_visible=bool(rng.random() < 0.5))
         hit = rng.random(nt) < 0.01
         t["scale"][hit] = rng.choice(SPECIAL, int(hit.sum()))
-        vertices, indices = ra.scene.make_geometry(t["meshes"])
+        vertices, indices = ra.scene.make_geometry(t["meshes"], ordering=str(rng.choice(["rows", "strips", "shuffled"])))
         pv = oracle.camera_pv(cam_pos=tuple(float(x) for x in rng.normal(0, 3, 3)), aspect=float(rng.uniform(0.7, 2.5)),
                               fovy_degrees=float(rng.uniform(30, 110)))
         r = oracle.run(t["pos"], t["rot"], t["scale"], t["mesh_id"], t["meshes"], t["planes"], t["cam_pos"], threads=8)

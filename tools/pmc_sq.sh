@@ -27,7 +27,7 @@ for f in glob.glob(f"{out}/**/*kernel_trace.csv", recursive=True):
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 m={k: sum(v)/len(v) for k,v in acc.items()}
 sha=hashlib.sha256()
-for f in ("instance_kernel.hpp","mip_api.hip"): sha.update(open("$ROOT/renderer_amd/csrc/"+f,"rb").read())
+for f in ("instance_kernel.hpp",): sha.update(open("$ROOT/renderer_amd/csrc/"+f,"rb").read())
 doc=dict(kernel_source_sha=sha.hexdigest()[:16], config=$CFG, launches_per_pass=20, counters=m,
          kernel_ns_under_pmc=(sum(dur)/len(dur) if dur else None),
          note="means per launch over all passes; SQ_*_CYCLES and SQ_WAIT_*/SQ_ACTIVE_* count quad-cycles summed over waves (MI355X_MICROARCH.md, rocprofv3 PMC slots); WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES")
