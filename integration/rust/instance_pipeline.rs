@@ -99,3 +99,54 @@ pub(crate) fn instance_pipeline(
     // cull_pass then copies scratch.cmds[..scratch.count] and scratch.count into
     // IndirectCommandsBuffer / IndirectCommandsCount instead of recording one dispatch per instance.
 }
+
+/// The zero-copy variant: the renderer's own allocations — ModelData.model_buffer
+/// (src/renderer.rs:1225-1265), IndirectCommandsBuffer / IndirectCommandsCount (cull_pipeline.rs:70-72) — exported once
+/// with vkGetMemoryFdKHR and mapped into the HIP device, and the frame ordered against the Vulkan queues by the pass's own
+/// timeline semaphores (src/renderer.rs:3757-3861) instead of a host wait. Built once, when the buffers exist:
+pub(crate) struct ZeroCopyTargets {
+    pub(crate) model: *mut std::ffi::c_void,        // mip_import_external_fd(ctx, fd_of(model_buffer), alloc_size, &mut ptr)
+    pub(crate) draw_cmds: *mut std::ffi::c_void,    // ... IndirectCommandsBuffer
+    pub(crate) draw_count: *mut u32,                // ... IndirectCommandsCount
+    pub(crate) bitmap: *mut u32,                    // a HIP-side allocation is fine: only this system reads it back
+    /// ComputeCull's timeline semaphore, exported with vkGetSemaphoreFdKHR and imported with
+    /// mip_import_external_semaphore_fd(ctx, fd, MIP_SEMAPHORE_TIMELINE, &mut sem)
+    pub(crate) cull_done: *mut mip_sys::MipExternalSemaphore,
+    /// the semaphore of the passes that READ these buffers (depth pre-pass / main pass), imported the same way
+    pub(crate) consumers_done: *mut mip_sys::MipExternalSemaphore,
+}
+unsafe impl Send for ZeroCopyTargets {}
+unsafe impl Sync for ZeroCopyTargets {}
+
+pub(crate) fn instance_pipeline_zero_copy(pipeline: Res<InstancePipeline>, targets: Res<ZeroCopyTargets>, camera: Res<Camera>,
+                                          frame_number: Res<crate::renderer::FrameNumber>) {
+    let ctx = pipeline.ctx.0;
+    let mut frame: mip_sys::MipFrame = unsafe { std::mem::zeroed() };
+    for (p, plane) in camera.frustum_planes.iter().enumerate() {
+        frame.planes[p * 4..p * 4 + 4].copy_from_slice(plane.as_slice());
+    }
+    frame.cam_pos.copy_from_slice(camera.position.coords.as_slice());
+    let out = mip_sys::MipOutputs {
+        model: targets.model,
+        visible_bitmap: targets.bitmap,
+        draw_cmds: targets.draw_cmds,
+        draw_count: targets.draw_count,
+        draw_index_total: std::ptr::null_mut(),
+        world_aabb: std::ptr::null_mut(),
+        flags: mip_sys::MIP_OUT_DEVICE | mip_sys::MIP_OUT_ASYNC,
+        reserved: 0,
+        culled_index_buffer: std::ptr::null_mut(),
+        culled_index_capacity: 0,
+        tlas_instances: std::ptr::null_mut(),
+    };
+    let n = frame_number.0 as u64;
+    unsafe {
+        // the draws of the previous frame that read these buffers have finished ...
+        assert_eq!(mip_sys::mip_wait_external(ctx, targets.consumers_done, n.saturating_sub(1)), mip_sys::MIP_OK);
+        // ... the frame runs on the library's stream ...
+        assert_eq!(mip_sys::mip_run(ctx, &frame, &out), mip_sys::MIP_OK);
+        // ... and ComputeCull's semaphore reaches this frame's value when its kernels have: the graphics submit waits on it
+        assert_eq!(mip_sys::mip_signal_external(ctx, targets.cull_done, n), mip_sys::MIP_OK);
+    }
+    // nothing is copied and nothing waits on the host; cull_pass keeps its frame-graph node only to carry the semaphore
+}

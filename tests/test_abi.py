@@ -134,10 +134,15 @@ def test_rust_binding_sizes_and_symbols_follow_the_header():
     rust_fns = set(re.findall(r"pub fn (mip_[a-z_]+)\(", text))
     assert rust_fns <= set(_declared_functions())
     assert {"mip_create", "mip_run", "mip_run_many", "mip_set_geometry", "mip_merge_draw_lists",
-            "mip_import_external_fd", "mip_release_external"} <= rust_fns
+            "mip_import_external_fd", "mip_release_external", "mip_merge_wire_lists", "mip_import_external_semaphore_fd",
+            "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore"} <= rust_fns
     # argument counts of the calls whose signature changed with ABI 2 (header vs Rust extern block)
     header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    for fn in ("mip_run_many", "mip_merge_draw_lists", "mip_import_external_fd"):
+    for fn in ("mip_run_many", "mip_merge_draw_lists", "mip_import_external_fd", "mip_merge_wire_lists", "mip_import_external_semaphore_fd",
+               "mip_wait_external", "mip_signal_external"):
         c_args = re.search(fn + r"\s*\(([^;]*?)\)\s*;", header, flags=re.S).group(1).count(",") + 1
         r_args = re.search(r"pub fn " + fn + r"\((.*?)\)\s*->", text, flags=re.S).group(1).count(",") + 1
         assert c_args == r_args, (fn, c_args, r_args)
+    # every call the shim text makes is declared in the binding
+    shim = open(os.path.join(ROOT, "integration", "rust", "instance_pipeline.rs")).read()
+    assert set(re.findall(r"mip_sys::(mip_[a-z_]+)\(", shim)) <= rust_fns
