@@ -132,38 +132,51 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
     in_block = chunk_count - b * kWireBlockCmds < kWireBlockCmds ? chunk_count - b * kWireBlockCmds : kWireBlockCmds;
     body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kWireBlockWords;
   };
-  // software pipeline: the records (and the block header) of a workgroup's NEXT block are in flight while it expands this one
-  uint32_t nb = 0, n_in_block = 0, n_chunk = 0, n_first_index = 0;
-  const uint32_t* n_body = nullptr;
-  uint2 n_rec = make_uint2(0u, 0u);
-  if (blockIdx.x < total_blocks) {
-    locate(blockIdx.x, nb, n_in_block, n_body);
-    n_chunk = chunk;
-    if (tid < n_in_block) n_rec = *reinterpret_cast<const uint2*>(n_body + kWireBlockHeaderWords + 2u * tid);
-    n_first_index = n_body[0];
-  }
-  for (uint32_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
-    const uint32_t b = nb, in_block = n_in_block, this_chunk = n_chunk, first_index = n_first_index;
-    const uint2 rec = n_rec;
-    const bool valid = tid < in_block;
-    if (blk + gridDim.x < total_blocks) {
-      locate(blk + gridDim.x, nb, n_in_block, n_body);
-      n_chunk = chunk;
-      n_rec = make_uint2(0u, 0u);
-      if (tid < n_in_block) n_rec = *reinterpret_cast<const uint2*>(n_body + kWireBlockHeaderWords + 2u * tid);
-      n_first_index = n_body[0];
+  // Software pipeline, two deep: while block i is expanded, the table entries of block i + 1 (gathers that depend on its
+  // records) and the records + header of block i + 2 are in flight.
+  struct Located { uint32_t b, in_block, chunk, first_index; uint2 rec; };
+  auto fetch_records = [&](uint32_t blk, Located& l) {
+    const uint32_t* body = nullptr;
+    l.rec = make_uint2(0u, 0u);
+    l.in_block = 0u;
+    l.first_index = 0u;
+    if (blk < total_blocks) {
+      locate(blk, l.b, l.in_block, body);
+      l.chunk = chunk;
+      if (tid < l.in_block) l.rec = *reinterpret_cast<const uint2*>(body + kWireBlockHeaderWords + 2u * tid);
+      l.first_index = body[0];
     }
-    uint32_t mesh = rec.y & 0x7fffffffu;
+  };
+  auto fetch_table = [&](const Located& l, uint32_t& len, int32_t& vertex_offset) {
+    uint32_t mesh = l.rec.y & 0x7fffffffu;
+    const bool valid = tid < l.in_block;
     if (mesh >= a.n_meshes) {  // never follow a corrupt record out of the table
       if (valid) raise_error(a.error_flag, kErrWireRecord);
       mesh = 0u;
     }
-    uint32_t len = 0u;
-    int32_t vertex_offset = 0;
+    len = 0u;
+    vertex_offset = 0;
     if (valid && a.n_meshes) {
-      len = (rec.y >> 31) ? a.meshes[mesh].len1 : a.meshes[mesh].len0;
+      len = (l.rec.y >> 31) ? a.meshes[mesh].len1 : a.meshes[mesh].len0;
       vertex_offset = a.mesh_draw[mesh].vertex_offset;
     }
+  };
+  Located cur{}, nxt{}, nxt2{};
+  uint32_t cur_len = 0, nxt_len = 0;
+  int32_t cur_vo = 0, nxt_vo = 0;
+  fetch_records(blockIdx.x, cur);
+  fetch_records(blockIdx.x + gridDim.x, nxt);
+  fetch_table(cur, cur_len, cur_vo);
+  for (uint32_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+    fetch_records(blk + 2u * gridDim.x, nxt2);   // block i + 2: records
+    fetch_table(nxt, nxt_len, nxt_vo);           // block i + 1: table entries
+    const uint32_t b = cur.b, in_block = cur.in_block, this_chunk = cur.chunk, first_index = cur.first_index;
+    const uint2 rec = cur.rec;
+    const bool valid = tid < in_block;
+    const uint32_t len = cur_len;
+    const int32_t vertex_offset = cur_vo;
+    cur = nxt; nxt = nxt2;
+    cur_len = nxt_len; cur_vo = nxt_vo;
     const uint32_t incl = wave_inclusive_scan(len);
     if (lane == 63u) s_wave_total[wave] = incl;
     __syncthreads();  // wave totals in; also: the previous block's copy-out has read s_out
