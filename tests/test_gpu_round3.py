@@ -648,3 +648,40 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
         count = int(scal[0].item())
         assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
         assert p.timings()["three_pass_frames"] == 2
+
+
+def test_kernel_wire_bytes_equal_the_committed_fixture(ra):
+    """The frame kernel's MIP_OUT_WIRE output for the committed golden inputs is the committed wire fixture, word for word
+    (live record slots and block headers), and the merge kernel expands it to the golden command bytes."""
+    import torch
+
+    from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
+    from renderer_amd.sharded import chunk_stride_bytes
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    w = np.load(os.path.join(here, "golden", "ext", "wire_4097_bases.npz"))
+    g = np.load(os.path.join(here, "golden", str(w["source"]) + ".npz"))
+    n = len(g["pos"])
+    dev = torch.device("cuda", 0)
+    stride = chunk_stride_bytes(n, wire=True)
+    chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
+    merged = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+    scal = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with ra.InstancePipeline(max_instances=n, max_meshes=len(g["meshes"])) as p:
+        p.set_mesh_table(g["meshes"])
+        p.set_instances(g["pos"], g["rot"], g["scale"], g["mesh_id"])
+        frame = make_frame(g["planes"], g["cam_pos"], first_instance_base=int(g["first_instance_base"]), first_index_base=int(g["first_index_base"]))
+        base = chunk.data_ptr()
+        p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire=True)
+        host = chunk.cpu().numpy().view(np.uint32)
+        count = int(host[0])
+        assert count == int(w["draw_count"]) and int(host[1]) == int(w["draw_index_total"])
+        got = host[SHARD_HEADER_BYTES // 4: SHARD_HEADER_BYTES // 4 + w["body"].size].reshape(-1, 516)
+        want = w["body"].reshape(-1, 516)
+        assert np.array_equal(got[:, 0], want[:, 0])
+        live = np.zeros((len(want), 256), bool)
+        live.reshape(-1)[:count] = True
+        assert np.array_equal(got[:, 4:].reshape(-1, 256, 2)[live], want[:, 4:].reshape(-1, 256, 2)[live])
+        p.merge_wire_lists(base, 1, stride, merged.data_ptr(), scal.data_ptr(), chunk_capacity=n)
+        assert merged[:count].cpu().numpy().tobytes() == g["draw_cmds"].tobytes()

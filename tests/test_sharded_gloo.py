@@ -184,3 +184,24 @@ def test_overflow_of_a_tightened_chunk_is_repaired_not_lost(world, n_global):
         mp.spawn(_worker_overflow, args=(world, os.path.join(d, "init"), n_global, d), nprocs=world, join=True)
         for r in range(world):
             assert os.path.exists(os.path.join(d, f"ok{r}"))
+
+
+def test_wire_fixture_pins_the_byte_layout():
+    """tests/golden/ext/wire_4097_bases.npz: the wire form of the committed golden frame mixed_4097_bases (bases 1000 /
+    0xFFFFF000, so the block headers wrap). The numpy statement of the format must still produce and expand these bytes."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import oracle
+    from cpu_pipeline import decode_wire, encode_wire
+
+    w = np.load(os.path.join(HERE, "golden", "ext", "wire_4097_bases.npz"))
+    g = np.load(os.path.join(HERE, "golden", str(w["source"]) + ".npz"))
+    cmds = g["draw_cmds"]
+    assert int(w["draw_count"]) == len(cmds) == 1116 and w["body"].size == 5 * 516
+    assert decode_wire(w["body"], len(cmds), g["meshes"]).tobytes() == cmds.tobytes()
+    inst = (cmds["firstInstance"] - np.uint32(g["first_instance_base"])).astype(np.int64)
+    far = np.array([oracle.pick_lod(2, g["cam_pos"], g["pos"][i]) for i in inst], np.uint32)
+    assert np.array_equal(encode_wire(cmds, g["mesh_id"][inst], far), w["body"])
+    # the layout itself: block b starts at word 516 b; word 0 = firstIndex of its first command; records from word 4
+    assert int(w["body"][0]) == int(cmds["firstIndex"][0]) and int(w["body"][516]) == int(cmds["firstIndex"][256])
+    assert int(w["body"][4]) == int(cmds["firstInstance"][0]) and int(w["body"][516 + 4 + 2]) == int(cmds["firstInstance"][257])
