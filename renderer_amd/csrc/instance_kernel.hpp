@@ -583,7 +583,7 @@ struct CensusArgs {
                   // [1] += number of instances whose mesh id is outside the table (the frame kernel gathers
                   //         meshes[mesh_id] unchecked: such an upload is refused, as mip_set_instances refuses it on the host)
 };
-// (static: this header is included by two translation units, mip_api.hip and triangle_tu.hip)
+// (static: this header is included by two translation units, mip_api.hip and stages_tu.hip)
 static __global__ __launch_bounds__(256) __attribute__((unused)) void mip_count_nonfinite_kernel(const CensusArgs a) {
   uint32_t bad = 0, bad_id = 0;
   for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.count; k += gridDim.x * 256u) {

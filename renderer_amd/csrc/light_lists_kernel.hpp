@@ -2,6 +2,7 @@
 #pragma once
 
 #include "instance_kernel.hpp"
+#include "stage_args.hpp"
 
 #pragma clang fp contract(off)
 
@@ -18,20 +19,6 @@ namespace mip {
 // One workgroup per 256 instances: positions and mesh data are read once, each light's 256
 // commands go through LDS so the stores are whole 1-KiB rows per wave (5 120 contiguous bytes
 // per tile and light). HBM-bound: 16 B read + n_lights * 20 B written per instance.
-constexpr uint32_t kMaxLights = 16;  // the shadow atlas is DIM x DIM = 4 x 4 maps, shadow_mapping.rs:24
-
-struct LightListArgs {
-  const float* pos;          // n*3
-  const uint32_t* mesh_id;   // n
-  const MeshEntry* meshes;   // m
-  const MeshDraw* mesh_draw; // m
-  uint32_t* out;             // n_lights * n * 5 words
-  uint32_t n;
-  uint32_t n_lights;
-  uint32_t first_instance_base;
-  float light[kMaxLights][3];
-};
-
 template <bool kAligned16>
 __global__ __launch_bounds__(kTile) void mip_light_draw_lists_kernel(const LightListArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t s_row[2][kTile * kCmdWords];

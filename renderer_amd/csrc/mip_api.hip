@@ -15,6 +15,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -302,14 +303,14 @@ const RcclApi* rccl() {
 // Which instantiation of the frame kernel a launch uses: the one without the literal cold path
 // whenever the census says every resident instance passes the finite test (and no per-instance
 // box override, which may be non-finite, is in play).
-using FrameKernel = void (*)(const mip::KernelArgs);
+using FrameKernel = mip::FrameKernelFn;
+// the stores-first order (kOrder == 1) is instantiated here; the commands-first order (3) in stages_tu.hip, built with
+// other flags — never both in one unit (stage_args.hpp)
 template <bool kBox, bool kGeneral, bool kWire>
 FrameKernel pick_order(bool ticketed, int order) {
-  if (ticketed)
-    return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1, kWire>
-                      : (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 3, kWire>;
-  return order == 1 ? (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1, kWire>
-                    : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 3, kWire>;
+  if (order != 1) return mip::frame_kernel_commands_first(ticketed, kBox, kGeneral, kWire);
+  return ticketed ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1, kWire>
+                  : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1, kWire>;
 }
 FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool wire, uint32_t* grid) {
   const uint32_t n_tiles = tiles_for(ctx->n);
@@ -906,7 +907,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       std::memcpy(k.level_start, ctx->joint_level_start, sizeof k.level_start);
       std::memcpy(k.level_inv, ctx->joint_level_inv, sizeof k.level_inv);
       const uint32_t per_block = 4u * (64u / ctx->n_joints);
-      hipLaunchKernelGGL(mip::mip_skinned_bounds_kernel, dim3((n + per_block - 1) / per_block), dim3(mip::kSkinBlock), 0, stream, k);
+      mip::launch_skinned_bounds((n + per_block - 1) / per_block, stream, k);
       MIP_HIP(ctx, hipGetLastError());
     }
     if (a.cmds && ctx->ordered_tiles && a.n_tiles > ctx->ordered_three_pass_min_tiles) {
@@ -1323,7 +1324,9 @@ static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const Mi
       std::memcpy(w.planes, frames[v].planes, sizeof w.planes);
       std::memcpy(w.cam, frames[v].cam_pos, sizeof w.cam);
     }
-    hipLaunchKernelGGL(mip::mip_cull_views_kernel, dim3(a.n_tiles), dim3(mip::kTile), 0, stream, a);
+    const bool general = ctx->nonfinite_instances != 0 || ctx->force_general;
+    if (general) ctx->timings.general_launches += 1;
+    mip::launch_cull_views(general, a.n_tiles, stream, a);
     MIP_HIP(ctx, hipGetLastError());
   }
   if (async) {
@@ -1470,10 +1473,7 @@ int32_t mip_light_draw_lists(MipContext* ctx, const float* light_pos_xyz, uint32
     a.first_instance_base = first_instance_base;
     std::memcpy(a.light, light_pos_xyz, (size_t)n_lights * 12);
     const bool aligned = (ctx->n % 4u) == 0 && ((uintptr_t)out_cmds % 16u) == 0;
-    if (aligned)
-      hipLaunchKernelGGL(mip::mip_light_draw_lists_kernel<true>, dim3(tiles_for(ctx->n)), dim3(mip::kTile), 0, ctx->stream, a);
-    else
-      hipLaunchKernelGGL(mip::mip_light_draw_lists_kernel<false>, dim3(tiles_for(ctx->n)), dim3(mip::kTile), 0, ctx->stream, a);
+    mip::launch_light_draw_lists(aligned, tiles_for(ctx->n), ctx->stream, a);
     MIP_HIP(ctx, hipGetLastError());
   }
   if (async) {
@@ -1797,6 +1797,14 @@ struct SemaphoreOp {
 };
 constexpr int64_t kSemaphoreWaitNs = 10ll * 1000 * 1000 * 1000;  // bounded like every other wait in the library
 
+// ioctl restarted when a signal interrupts it (what libdrm's drmIoctl does; the waits carry an ABSOLUTE deadline)
+static int drm_ioctl(int fd, unsigned long request, void* arg) {
+  int rc;
+  do rc = ioctl(fd, request, arg);
+  while (rc == -1 && (errno == EINTR || errno == EAGAIN));
+  return rc;
+}
+
 static void semaphore_host_fn(void* p) {
   SemaphoreOp* op = static_cast<SemaphoreOp*>(p);
   uint32_t handle = op->handle;
@@ -1808,12 +1816,12 @@ static void semaphore_host_fn(void* p) {
       a.handles = (uintptr_t)&handle;
       a.points = (uintptr_t)&point;
       a.count_handles = 1;
-      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL, &a);
+      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL, &a);
     } else {
       drm_syncobj_array a{};
       a.handles = (uintptr_t)&handle;
       a.count_handles = 1;
-      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_SIGNAL, &a);
+      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_SIGNAL, &a);
     }
   } else {
     timespec now;
@@ -1826,19 +1834,19 @@ static void semaphore_host_fn(void* p) {
       w.timeout_nsec = deadline;
       w.count_handles = 1;
       w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;  // the point may not have been submitted yet
-      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_WAIT, &w);
+      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_WAIT, &w);
     } else {
       drm_syncobj_wait w{};
       w.handles = (uintptr_t)&handle;
       w.timeout_nsec = deadline;
       w.count_handles = 1;
       w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;
-      rc = ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_WAIT, &w);
+      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_WAIT, &w);
       if (rc == 0) {  // a binary semaphore is consumed by its wait
         drm_syncobj_array a{};
         a.handles = (uintptr_t)&handle;
         a.count_handles = 1;
-        (void)ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_RESET, &a);
+        (void)drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_RESET, &a);
       }
     }
   }
@@ -1883,7 +1891,7 @@ int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t k
     }
     drm_syncobj_handle h{};
     h.fd = fd;
-    if (ctx->drm_fd < 0 || ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE, &h) != 0 || !h.handle)
+    if (ctx->drm_fd < 0 || drm_ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE, &h) != 0 || !h.handle)
       return fail(ctx, MIP_ERR_DEVICE, "hipImportExternalSemaphore(%s) failed: %s; and the fd is not a DRM sync object either (%s)",
                   kind == MIP_SEMAPHORE_TIMELINE ? "TimelineSemaphoreFd" : "OpaqueFd", hipGetErrorString(e),
                   ctx->drm_fd < 0 ? "no render node could be opened" : "DRM_IOCTL_SYNCOBJ_FD_TO_HANDLE refused it");

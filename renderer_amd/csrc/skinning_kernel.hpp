@@ -2,6 +2,7 @@
 #pragma once
 
 #include "instance_kernel.hpp"
+#include "stage_args.hpp"
 
 #pragma clang fp contract(off)
 
@@ -36,31 +37,6 @@ namespace mip {
 // through LDS so that every store instruction is 1 KiB contiguous: 40 B read + 64 B written per
 // joint. What bounds the kernel is workgroup lifetime x resident workgroups (its phases are
 // separated by barriers), so registers and LDS are kept small: 66 VGPRs, 18 KB, 7 waves per SIMD.
-constexpr uint32_t kMaxJoints = 32;
-constexpr uint32_t kPoseWords = 10;  // t xyz, q ijkw, s xyz
-constexpr uint32_t kSkinBlock = 256;
-
-struct alignas(16) JointEntry {
-  float ibm[12];     // rows 0..2 of inverseBindMatrices[k], column-major 3x4
-  float box[6];      // min xyz, max xyz of the bind-pose vertices weighted to this joint; min > max: none
-  int32_t parent;    // < k, or -1
-  uint32_t sorted;   // entry i: the i-th joint in depth order and its parent, joint | parent << 8
-};
-static_assert(sizeof(JointEntry) == 80, "JointEntry layout");
-
-struct SkinArgs {
-  const float* poses;          // n * J * 10, 8-byte aligned
-  const JointEntry* joints;    // J
-  float4* palette;             // n * J * 4 (mat4 column-major) or null
-  float* local_box;            // n*8: {min xyz, -, max xyz, -} of the posed mesh (the fold's raw result; slots 3 and 7 unused)
-  uint32_t n;
-  uint32_t n_joints;
-  uint32_t max_depth;
-  uint32_t inv_joints;                      // ceil(2^16 / J): x / J == (x * inv) >> 16 for x < 256
-  uint32_t level_inv[kMaxJoints + 1];       // ceil(2^16 / joints at depth d)
-  uint8_t level_start[kMaxJoints + 2];      // depth d owns sorted entries [level_start[d], level_start[d+1])
-};
-
 __device__ __forceinline__ void affine_mul(const float (&a)[12], const float (&b)[12], float (&o)[12]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c)

@@ -1,0 +1,165 @@
+// stage_args.hpp — argument blocks and host-side launchers of every kernel that is built in the library's SECOND
+// translation unit (stages_tu.hip): the per-triangle stage (row f-1), the multi-view cull and the shadow-pass lists
+// (row f-4), the skinning extension, and the commands-first order of the frame kernel (small launches).
+// That unit is compiled with -fno-slp-vectorize. Under plain -O3 the SLP vectoriser packs pairs of independent f32
+// operations into v_pk_mul_f32 / v_pk_add_f32 and pays for it with one v_mov_b32 per operand pair (115 moves beside
+// 136 packed operations per 64-triangle step in round 2's ISA of the triangle kernel; 136 moves in the multi-view
+// kernel); on gfx950 a packed f32 instruction takes twice the issue time of a plain one, so packing buys nothing and
+// the moves are pure cost. Measured per kernel (profiles/r03_triangle_no_slp_ab.txt, r03_no_slp_by_kernel.txt): per-
+// triangle stage -7 %, skinning -11 .. -16 %, four views -6 %, light lists x16 -4 %, frame kernel 100 k .. 800 k
+// -2 .. -4 %; the stores-first frame kernel of large launches (the headline) is the one kernel that is not faster
+// that way and stays in mip_api.hip, which sees only this header.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+namespace mip {
+
+struct MeshEntry;   // instance_kernel.hpp
+struct MeshDraw;
+struct KernelArgs;
+
+// ---- row f-1: per-triangle stage (triangle_kernels.hpp) ----
+struct TriangleArgs {
+  uint32_t* cmds;                 // compacted commands of the instance kernel; indexCount is rewritten
+  const uint32_t* count;          // number of commands (device)
+  const uint32_t* src_index_offset;
+  const float4* model;            // n x mat4 of the same frame
+  const float* vertices;          // consolidated positions, packed vec3
+  const uint32_t* indices;        // consolidated indices
+  uint32_t* out_indices;          // culled index stream (uvec3 out_index_buffer[])
+  unsigned long long capacity;    // in indices
+  uint32_t first_instance_base;
+  uint32_t* error_flag;
+  uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
+  uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
+  float pv[16];
+};
+
+struct RecompactArgs {
+  const uint32_t* in_cmds;
+  const uint32_t* in_count;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+};
+
+struct RecompactWideArgs {
+  const uint32_t* in_cmds;
+  const uint32_t* in_count;
+  uint32_t* out_cmds;
+  uint32_t* out_count;
+  uint32_t* block_base;   // one word per 1024 commands: survivors in the block, then their exclusive prefix
+  uint32_t n_blocks;
+};
+
+constexpr uint32_t kTriParts = 16;
+constexpr uint32_t kTriPartMaxT = 8;  // triangles per thread and part: commands up to 16 * 256 * 8 = 32 768 triangles
+
+struct TrianglePartsArgs {
+  TriangleArgs t;
+  unsigned long long* part_status;  // [commands][kTriParts] granules {epoch : 32 | survivors : 32}
+  uint32_t epoch;                   // unique per launch on this frame slot, never 0
+};
+
+// Launchers (defined in stages_tu.hip). Each enqueues one kernel on `stream`; errors surface through hipGetLastError.
+void launch_triangle_cull_waves(uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
+void launch_triangle_cull_block(uint32_t threads /* 256 | 512 | 1024 */, uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
+void launch_triangle_cull_parts(uint32_t blocks, hipStream_t stream, const TrianglePartsArgs& a);
+void launch_recompact(hipStream_t stream, const RecompactArgs& a);
+void launch_recompact_wide(hipStream_t stream, const RecompactWideArgs& a);  // count, scan, scatter
+
+// ---- row f-4: shadow-pass draw lists (light_lists_kernel.hpp) ----
+constexpr uint32_t kMaxLights = 16;  // the shadow atlas is DIM x DIM = 4 x 4 maps, shadow_mapping.rs:24
+
+struct LightListArgs {
+  const float* pos;          // n*3
+  const uint32_t* mesh_id;   // n
+  const MeshEntry* meshes;   // m
+  const MeshDraw* mesh_draw; // m
+  uint32_t* out;             // n_lights * n * 5 words
+  uint32_t n;
+  uint32_t n_lights;
+  uint32_t first_instance_base;
+  float light[kMaxLights][3];
+};
+
+void launch_light_draw_lists(bool aligned16, uint32_t tiles, hipStream_t stream, const LightListArgs& a);
+
+// ---- extension, BASELINE config 5: skinned instances (skinning_kernel.hpp) ----
+constexpr uint32_t kMaxJoints = 32;
+constexpr uint32_t kPoseWords = 10;  // t xyz, q ijkw, s xyz
+constexpr uint32_t kSkinBlock = 256;
+
+struct alignas(16) JointEntry {
+  float ibm[12];     // rows 0..2 of inverseBindMatrices[k], column-major 3x4
+  float box[6];      // min xyz, max xyz of the bind-pose vertices weighted to this joint; min > max: none
+  int32_t parent;    // < k, or -1
+  uint32_t sorted;   // entry i: the i-th joint in depth order and its parent, joint | parent << 8
+};
+static_assert(sizeof(JointEntry) == 80, "JointEntry layout");
+
+struct SkinArgs {
+  const float* poses;          // n * J * 10, 8-byte aligned
+  const JointEntry* joints;    // J
+  float4* palette;             // n * J * 4 (mat4 column-major) or null
+  float* local_box;            // n*8: {min xyz, -, max xyz, -} of the posed mesh (the fold's raw result; slots 3 and 7 unused)
+  uint32_t n;
+  uint32_t n_joints;
+  uint32_t max_depth;
+  uint32_t inv_joints;                      // ceil(2^16 / J): x / J == (x * inv) >> 16 for x < 256
+  uint32_t level_inv[kMaxJoints + 1];       // ceil(2^16 / joints at depth d)
+  uint8_t level_start[kMaxJoints + 2];      // depth d owns sorted entries [level_start[d], level_start[d+1])
+};
+
+void launch_skinned_bounds(uint32_t blocks, hipStream_t stream, const SkinArgs& a);
+
+// ---- row f-4: up to four culled views per launch (views_kernel.hpp) ----
+constexpr uint32_t kMaxViews = 4;
+
+struct ViewArgs {
+  // prefix state of this view (publish_aggregate / resolve_prefix read these names)
+  unsigned long long* status0;
+  unsigned long long* acc1;
+  unsigned long long* start1;
+  uint32_t groups_cap;
+  uint32_t group_shift;
+  uint32_t epoch;
+  uint32_t* error_flag;
+#ifdef MIP_DEBUG_STAMPS
+  unsigned long long* stamps;  // never set: keeps the shared prefix routines compiling in the diagnostic build
+#endif
+  // outputs
+  uint32_t* bitmap;       // ceil(n/32) words or null
+  uint32_t* cmds;         // n*5 words
+  uint32_t* draw_count;
+  uint32_t* index_total;  // or null
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  float planes[24];
+  float cam[3];
+};
+
+struct ViewsArgs {
+  const float* pos;
+  const float4* rot;
+  const float* scale;
+  const uint32_t* mesh_id;
+  const MeshEntry* meshes;
+  const MeshDraw* mesh_draw;
+  uint32_t n;
+  uint32_t n_tiles;
+  uint32_t bitmap_words;
+  uint32_t n_views;
+  ViewArgs view[kMaxViews];
+};
+
+void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const ViewsArgs& a);
+
+// ---- rows a-1 .. a-7, commands-first order (kOrder == 3 of instance_kernel.hpp: launches below ~0.9 M instances) ----
+// The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in mip_api.hip.
+using FrameKernelFn = void (*)(const KernelArgs);
+FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, bool wire);
+
+}  // namespace mip

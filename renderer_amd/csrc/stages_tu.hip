@@ -1,0 +1,65 @@
+// stages_tu.hip — the library's second translation unit: the kernels that are faster without the SLP vectoriser
+// (per-triangle stage, multi-view cull, shadow-pass lists, skinning, the commands-first frame kernel) and their
+// launchers. Built with the library's floating-point flags PLUS -fno-slp-vectorize (stage_args.hpp has the numbers).
+#include "triangle_kernels.hpp"
+#include "light_lists_kernel.hpp"
+#include "skinning_kernel.hpp"
+#include "views_kernel.hpp"
+
+namespace mip {
+
+void launch_triangle_cull_waves(uint32_t blocks, hipStream_t stream, const TriangleArgs& a) {
+  hipLaunchKernelGGL(mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+void launch_triangle_cull_block(uint32_t threads, uint32_t blocks, hipStream_t stream, const TriangleArgs& a) {
+  if (threads == 256u) hipLaunchKernelGGL(mip_triangle_cull_block_kernel<256>, dim3(blocks), dim3(256), 0, stream, a);
+  else if (threads == 512u) hipLaunchKernelGGL(mip_triangle_cull_block_kernel<512>, dim3(blocks), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL(mip_triangle_cull_block_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, a);
+}
+
+void launch_triangle_cull_parts(uint32_t blocks, hipStream_t stream, const TrianglePartsArgs& a) {
+  hipLaunchKernelGGL(mip_triangle_cull_parts_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+void launch_recompact(hipStream_t stream, const RecompactArgs& a) {
+  hipLaunchKernelGGL(mip_recompact_kernel, dim3(1), dim3(1024), 0, stream, a);
+}
+
+void launch_recompact_wide(hipStream_t stream, const RecompactWideArgs& a) {
+  hipLaunchKernelGGL(mip_recompact_count_kernel, dim3(a.n_blocks), dim3(1024), 0, stream, a);
+  hipLaunchKernelGGL(mip_recompact_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+  hipLaunchKernelGGL(mip_recompact_scatter_kernel, dim3(a.n_blocks), dim3(1024), 0, stream, a);
+}
+
+void launch_light_draw_lists(bool aligned16, uint32_t tiles, hipStream_t stream, const LightListArgs& a) {
+  if (aligned16) hipLaunchKernelGGL(mip_light_draw_lists_kernel<true>, dim3(tiles), dim3(kTile), 0, stream, a);
+  else hipLaunchKernelGGL(mip_light_draw_lists_kernel<false>, dim3(tiles), dim3(kTile), 0, stream, a);
+}
+
+void launch_skinned_bounds(uint32_t blocks, hipStream_t stream, const SkinArgs& a) {
+  hipLaunchKernelGGL(mip_skinned_bounds_kernel, dim3(blocks), dim3(kSkinBlock), 0, stream, a);
+}
+
+void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const ViewsArgs& a) {
+  if (general) hipLaunchKernelGGL(mip_cull_views_kernel<true>, dim3(tiles), dim3(kTile), 0, stream, a);
+  else hipLaunchKernelGGL(mip_cull_views_kernel<false>, dim3(tiles), dim3(kTile), 0, stream, a);
+}
+
+// Every kOrder == 3 instantiation of the frame kernel lives here and only here (mip_api.hip instantiates kOrder == 1):
+// an instantiation referenced from both units would be registered twice under one host stub.
+namespace {
+template <bool kBox, bool kGeneral, bool kWire>
+FrameKernelFn commands_first(bool ticketed) {
+  return ticketed ? (FrameKernelFn)mip_instance_pipeline_kernel<true, kBox, kGeneral, 3, kWire>
+                  : (FrameKernelFn)mip_instance_pipeline_kernel<false, kBox, kGeneral, 3, kWire>;
+}
+}  // namespace
+
+FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, bool wire) {
+  if (box_override) return commands_first<true, true, false>(ticketed);  // skinned frames: always general, never wire
+  if (wire) return general ? commands_first<false, true, true>(ticketed) : commands_first<false, false, true>(ticketed);
+  return general ? commands_first<false, true, false>(ticketed) : commands_first<false, false, false>(ticketed);
+}
+
+}  // namespace mip

@@ -2,7 +2,7 @@
 #pragma once
 
 #include "instance_kernel.hpp"
-#include "triangle_args.hpp"
+#include "stage_args.hpp"
 
 #pragma clang fp contract(off)
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "instance_kernel.hpp"
+#include "stage_args.hpp"
 
 #pragma clang fp contract(off)
 
@@ -17,45 +18,29 @@ namespace mip {
 // (same one-hop scheme as the instance kernel, one state per view) is resolved and its commands copied
 // out by wave v of the workgroup, so the four hops run side by side. The matrices are not written here
 // (they do not depend on the view; the frame's mip_run writes them).
-constexpr uint32_t kMaxViews = 4;
+// The plane test of coarse_culled with the subtraction folded into the comparison: `sd - e > 0` and `sd > e` agree for
+// every pair of floats while subnormals are kept (a difference of two floats that underflows is exact, so its sign
+// is the comparison's; inf - inf and NaN give false on both sides) — one VALU instruction less per plane, and this
+// kernel is bound by VALU issue (4 views: ~750 instructions per wave).
+__device__ __forceinline__ bool view_culled(const float (&h)[3], const float (&c)[3], const float (&planes)[24]) {
+  bool outside = false;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const float nx = planes[p * 4 + 0], ny = planes[p * 4 + 1], nz = planes[p * 4 + 2], d = planes[p * 4 + 3];
+    const float e = h[0] * fabsf(nx) + h[1] * fabsf(ny) + h[2] * fabsf(nz);
+    float a0 = nx * c[0];
+    float a1 = ny * c[1];
+    const float a2 = nz * c[2];
+    a0 += a2;
+    a1 += d;
+    const float sd = a0 + a1;
+    outside = outside || (sd > e);
+  }
+  return outside;
+}
 
-struct ViewArgs {
-  // prefix state of this view (publish_aggregate / resolve_prefix read these names)
-  unsigned long long* status0;
-  unsigned long long* acc1;
-  unsigned long long* start1;
-  uint32_t groups_cap;
-  uint32_t group_shift;
-  uint32_t epoch;
-  uint32_t* error_flag;
-#ifdef MIP_DEBUG_STAMPS
-  unsigned long long* stamps;  // never set: keeps the shared prefix routines compiling in the diagnostic build
-#endif
-  // outputs
-  uint32_t* bitmap;       // ceil(n/32) words or null
-  uint32_t* cmds;         // n*5 words
-  uint32_t* draw_count;
-  uint32_t* index_total;  // or null
-  uint32_t first_instance_base;
-  uint32_t first_index_base;
-  float planes[24];
-  float cam[3];
-};
-
-struct ViewsArgs {
-  const float* pos;
-  const float4* rot;
-  const float* scale;
-  const uint32_t* mesh_id;
-  const MeshEntry* meshes;
-  const MeshDraw* mesh_draw;
-  uint32_t n;
-  uint32_t n_tiles;
-  uint32_t bitmap_words;
-  uint32_t n_views;
-  ViewArgs view[kMaxViews];
-};
-
+// kGeneral = false: the upload-time census found every instance finite and separable-safe (as for the frame kernel).
+template <bool kGeneral>
 __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArgs a) {
   __shared__ uint32_t s_cmd[kMaxViews][kTile * kCmdWords];
   __shared__ uint32_t s_wave_count[kMaxViews][kWaves], s_wave_sum[kMaxViews][kWaves];
@@ -78,32 +63,41 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   MeshEntry mb;
   mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
   mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
-  const uint4 md = *reinterpret_cast<const uint4*>(&a.mesh_draw[mesh]);
+  const int32_t vertex_offset = a.mesh_draw[mesh].vertex_offset;
   float r[3][3];
   quat_to_rotation(q.x, q.y, q.z, q.w, r);
-  // the three arithmetic tiers of the instance kernel, chosen per wave (instance_kernel.hpp)
-  const float mag = finite_magnitude(r, px, py, pz, sc);
-  const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
-  const bool all_finite = mag < kFiniteLimit;
-  const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
   Instance inst;
-  if (__builtin_expect(__any(!separable), 0)) {
-    if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
-    else instance_fast(r, px, py, pz, sc, mb, inst);
+  if constexpr (kGeneral) {
+    // the three arithmetic tiers of the instance kernel, chosen per wave (instance_kernel.hpp)
+    const float mag = finite_magnitude(r, px, py, pz, sc);
+    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
+    const bool all_finite = mag < kFiniteLimit;
+    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
+    if (__builtin_expect(__any(!separable), 0)) {
+      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
+      else instance_fast(r, px, py, pz, sc, mb, inst);
+    } else {
+      instance_separable(r, px, py, pz, sc, mb, inst);
+    }
   } else {
     instance_separable(r, px, py, pz, sc, mb, inst);
+  }
+  float box_h[3], box_c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    box_h[k] = (inst.maxs[k] - inst.mins[k]) * 0.5f;  // AABB::half_extents
+    box_c[k] = (inst.mins[k] + inst.maxs[k]) * 0.5f;  // AABB::center
   }
 
   // ---- per view: frustum test, LOD, wave-level compaction offsets ----
   bool keep[kMaxViews];
   uint32_t len[kMaxViews], rank[kMaxViews], excl_sum[kMaxViews];
   unsigned long long vis_mask[kMaxViews];
-  (void)md.y;
 #pragma unroll
   for (uint32_t v = 0; v < kMaxViews; ++v) {
     keep[v] = false; len[v] = 0; rank[v] = 0; excl_sum[v] = 0; vis_mask[v] = 0;
     if (v < a.n_views) {
-      const bool visible = active && !coarse_culled(inst, a.view[v].planes);
+      const bool visible = active && !view_culled(box_h, box_c, a.view[v].planes);
       const float dx = a.view[v].cam[0] - px, dy = a.view[v].cam[1] - py, dz = a.view[v].cam[2] - pz;
       const float dist_sq = dx * dx + dy * dy + dz * dz;
       const bool far_lod = dist_sq > kLodDistSqThreshold;
@@ -148,12 +142,51 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
       c[0] = len[v];                                // indexCount
       c[1] = 1u;                                    // instanceCount
       c[2] = off_sum + excl_sum[v];                 // firstIndex (tile-relative)
-      c[3] = md.x;                                  // vertexOffset
+      c[3] = (uint32_t)vertex_offset;               // vertexOffset
       c[4] = a.view[v].first_instance_base + i;     // firstInstance = draw_index
     }
   }
   __syncthreads();
 
+#ifdef MIP_VIEWS_COOP_COPY
+  // ---- wave v resolves view v's prefix; then the whole workgroup copies every view out ----
+  __shared__ uint32_t s_base_count[kMaxViews], s_base_sum[kMaxViews], s_tile_count[kMaxViews];
+  {
+    const uint32_t my_view = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    if (my_view < a.n_views) {
+      const ViewArgs& view = a.view[my_view];
+      uint32_t tile_count = 0, tile_sum = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kWaves; ++w) { tile_count += s_wave_count[my_view][w]; tile_sum += s_wave_sum[my_view][w]; }
+      uint32_t base_count = 0, base_sum = 0;
+      if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum);
+      if (lane == 0) {
+        if (tile == a.n_tiles - 1u) {
+          *view.draw_count = base_count + tile_count;
+          if (view.index_total) *view.index_total = base_sum + tile_sum;
+        }
+        s_base_count[my_view] = base_count;
+        s_base_sum[my_view] = base_sum + view.first_index_base;
+        s_tile_count[my_view] = tile_count;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t v = 0; v < kMaxViews; ++v) {
+    if (v < a.n_views) {
+      const uint32_t first_index_add = s_base_sum[v];
+      uint32_t* out = a.view[v].cmds + (size_t)s_base_count[v] * kCmdWords;
+      const uint32_t words = s_tile_count[v] * kCmdWords;
+      for (uint32_t j = tid; j < words; j += kTile) {
+        const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
+        uint32_t val = s_cmd[v][j];
+        if (f == 2u) val += first_index_add;
+        out[j] = val;
+      }
+    }
+  }
+#else
   // ---- wave v finishes view v: prefix over the earlier tiles, coalesced copy-out ----
   const uint32_t my_view = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);  // scalar: the view's words are scalar loads
   if (my_view >= a.n_views) return;
@@ -176,6 +209,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
     if (f == 2u) val += first_index_add;
     out[j] = val;
   }
+#endif
 }
 
 }  // namespace mip
