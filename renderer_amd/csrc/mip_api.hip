@@ -920,9 +920,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       ta.k = a;
       ta.tile_agg = sl.d_tile_agg;
       const bool general = skinned || ctx->nonfinite_instances != 0 || ctx->force_general;
-      if (skinned) hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<true, true>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
-      else if (general) hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<false, true>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
-      else hipLaunchKernelGGL((mip::mip_tile_aggregate_kernel<false, false>), dim3(a.n_tiles), dim3(mip::kTile), 0, stream, ta);
+      mip::launch_tile_aggregate(skinned, general, a.n_tiles, stream, ta);
       mip::TileScanArgs ts{};
       ts.tile_agg = sl.d_tile_agg;
       ts.tile_prefix = sl.d_tile_prefix;

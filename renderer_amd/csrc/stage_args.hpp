@@ -20,6 +20,7 @@ namespace mip {
 struct MeshEntry;   // instance_kernel.hpp
 struct MeshDraw;
 struct KernelArgs;
+struct TileAggregateArgs;
 
 // ---- row f-1: per-triangle stage (triangle_kernels.hpp) ----
 struct TriangleArgs {
@@ -161,5 +162,7 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in mip_api.hip.
 using FrameKernelFn = void (*)(const KernelArgs);
 FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, bool wire);
+// first of the three wait-free launches of a large ordered-tiles frame (mip_tile_aggregate_kernel, instance_kernel.hpp)
+void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a);
 
 }  // namespace mip

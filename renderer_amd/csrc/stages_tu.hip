@@ -62,4 +62,10 @@ FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool
   return general ? commands_first<false, true, false>(ticketed) : commands_first<false, false, false>(ticketed);
 }
 
+void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a) {
+  if (box_override) hipLaunchKernelGGL((mip_tile_aggregate_kernel<true, true>), dim3(tiles), dim3(kTile), 0, stream, a);
+  else if (general) hipLaunchKernelGGL((mip_tile_aggregate_kernel<false, true>), dim3(tiles), dim3(kTile), 0, stream, a);
+  else hipLaunchKernelGGL((mip_tile_aggregate_kernel<false, false>), dim3(tiles), dim3(kTile), 0, stream, a);
+}
+
 }  // namespace mip
