@@ -109,6 +109,7 @@ struct MipContext {
   // skinned extension (mip_set_skeleton / mip_set_poses / mip_run_skinned)
   mip::JointEntry* d_joints = nullptr;
   uint32_t n_joints = 0, max_joint_depth = 0;
+  float joint_box_bound = INFINITY;  // 3 * max |joint_box| + 1, +inf while a joint box holds a non-finite value (SkinArgs.box_bound)
   uint8_t joint_level_start[mip::kMaxJoints + 2] = {0};
   uint32_t joint_level_inv[mip::kMaxJoints + 1] = {0};
   float* d_poses_owned = nullptr;
@@ -903,6 +904,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       k.n = n;
       k.n_joints = ctx->n_joints;
       k.max_depth = ctx->max_joint_depth;
+      k.box_bound = ctx->joint_box_bound;
       k.inv_joints = (65536u + ctx->n_joints - 1u) / ctx->n_joints;
       std::memcpy(k.level_start, ctx->joint_level_start, sizeof k.level_start);
       std::memcpy(k.level_inv, ctx->joint_level_inv, sizeof k.level_inv);
@@ -1410,6 +1412,15 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
   }
   ctx->n_joints = n_joints;
   ctx->max_joint_depth = max_depth;
+  {
+    float box_max = 0.0f;
+    bool finite = true;
+    for (size_t q = 0; q < (size_t)n_joints * 6; ++q) {
+      finite = finite && std::isfinite(joint_box[q]);
+      box_max = std::fmax(box_max, std::fabs(joint_box[q]));
+    }
+    ctx->joint_box_bound = finite ? 3.0f * box_max + 1.0f : INFINITY;
+  }
   std::memcpy(ctx->joint_level_start, level_start, sizeof level_start);
   std::memcpy(ctx->joint_level_inv, level_inv, sizeof level_inv);
   return MIP_OK;

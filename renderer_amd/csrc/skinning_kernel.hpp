@@ -154,16 +154,37 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
   }
 
   // ---- this joint's share of the posed box ----
+  // The eight corners of the joint box under J_k, folded — or, whenever no value on the way can overflow or be NaN,
+  // the same fold WITHOUT the corners (instance_kernel.hpp, instance_separable: fl(a + b) is monotone in each operand,
+  // so the smallest corner coordinate is the sum of the three smallest products; equal up to the sign of a zero).
+  // Guard, per wave: S = sum |J_k entries| (a NaN or an infinity anywhere makes it NaN or inf), and every product and
+  // partial sum of the fold is bounded by S * (3 * max|box| + 1) = S * box_bound. 54 + 13 instead of 126 vector
+  // instructions per lane; this kernel is bound by VALU issue.
   float lo[3] = {3.40282347e+38f, 3.40282347e+38f, 3.40282347e+38f};
   float hi[3] = {-3.40282347e+38f, -3.40282347e+38f, -3.40282347e+38f};
+  float mag = fabsf(Jm[0]);
+#pragma unroll
+  for (int q = 1; q < 12; ++q) mag += fabsf(Jm[q]);
+  const bool separable = mag * a.box_bound < 1.0e38f;
   if (!(box[0] > box[3] || box[1] > box[4] || box[2] > box[5])) {
+    if (__builtin_expect(__any(!separable), 0)) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {  // corner order of src/ecs.rs:149-160
-      const float x = box[(c & 1) ? 3 : 0], z = box[(c & 2) ? 5 : 2], y = box[(c & 4) ? 4 : 1];
-      float v[3];
+      for (int c = 0; c < 8; ++c) {  // corner order of src/ecs.rs:149-160
+        const float x = box[(c & 1) ? 3 : 0], z = box[(c & 2) ? 5 : 2], y = box[(c & 4) ? 4 : 1];
+        float v[3];
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) v[rr] = Jm[0 * 3 + rr] * x + Jm[1 * 3 + rr] * y + Jm[2 * 3 + rr] * z + Jm[9 + rr];
-      fold_corner(v, lo, hi);
+        for (int rr = 0; rr < 3; ++rr) v[rr] = Jm[0 * 3 + rr] * x + Jm[1 * 3 + rr] * y + Jm[2 * 3 + rr] * z + Jm[9 + rr];
+        fold_corner(v, lo, hi);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const float x0 = Jm[0 * 3 + rr] * box[0], x1 = Jm[0 * 3 + rr] * box[3];
+        const float y0 = Jm[1 * 3 + rr] * box[1], y1 = Jm[1 * 3 + rr] * box[4];
+        const float z0 = Jm[2 * 3 + rr] * box[2], z1 = Jm[2 * 3 + rr] * box[5];
+        lo[rr] = fminf(x0, x1) + fminf(y0, y1) + fminf(z0, z1) + Jm[9 + rr];
+        hi[rr] = fmaxf(x0, x1) + fmaxf(y0, y1) + fmaxf(z0, z1) + Jm[9 + rr];
+      }
     }
   }
   if (valid) {

@@ -110,6 +110,7 @@ struct SkinArgs {
   uint32_t n_joints;
   uint32_t max_depth;
   uint32_t inv_joints;                      // ceil(2^16 / J): x / J == (x * inv) >> 16 for x < 256
+  float box_bound;                          // 3 * max |joint box coordinate| + 1 over the skeleton; +inf: some box is not finite
   uint32_t level_inv[kMaxJoints + 1];       // ceil(2^16 / joints at depth d)
   uint8_t level_start[kMaxJoints + 2];      // depth d owns sorted entries [level_start[d], level_start[d+1])
 };
