@@ -328,11 +328,28 @@ def light_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
     }
 
 
-def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
+def views_pmc(n):
+    """Counters per launch of the multi-view kernel from the committed PMC pass (tools/pmc_views.sh), if it was taken from
+    this source of views_kernel.hpp."""
+    import glob
+
+    sha = hashlib.sha256(open(os.path.join(ROOT, "renderer_amd", "csrc", "views_kernel.hpp"), "rb").read()).hexdigest()[:16]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*views*pmc_summary.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("instances") == n and doc.get("views") == 4 and doc.get("views_source_sha") == sha:
+            return doc, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, stream):
     """Row f-4, "per-light cull lists": four culled views (the reference's light positions as LOD reference
-    points, the default frustum moved to each) of the scene in one launch, mip_run_views."""
+    points, the default frustum moved to each) of the scene in one launch, mip_run_views; HIP-event samples on the
+    launch stream."""
     n = s["n"]
-    p = make_pipe(renderer_amd, s, local_rank)
+    p = make_pipe(renderer_amd, s, local_rank, stream=stream)
     eyes = np.array([[0, 1, 2], [30, 20, -40.1], [0.1, 17, -0.1], [-30, 20, 40.1]], np.float32)
     frames, outs, keep = [], [], []
     for e in eyes:
@@ -348,19 +365,30 @@ def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank):
         outs.append(p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4,
                                       visible_bitmap=bitmap.data_ptr()))
     torch.cuda.synchronize()
-    for _ in range(20):
-        p.run_views(frames, outs)
+    ev, wall = event_samples(torch, lambda: p.run_views(frames, outs), 20, 20, 30)
     p.wait()
     counts = [int(k[1][0].item()) for k in keep]
-    t0 = time.perf_counter()
-    for _ in range(300):
-        p.run_views(frames, outs)
-    p.wait()
-    dt = (time.perf_counter() - t0) / 300
     p.close()
-    return {"instances": n, "views": len(eyes), "ms_per_launch": dt * 1e3, "instance_views_per_s": n * len(eyes) / dt,
-            "commands_per_view": counts,
-            "note": "one launch: instance data read once, matrix + world box built once, per view plane test + compaction"}
+    ms = float(np.median(ev))
+    nbytes = 36 * n + sum(20 * c for c in counts) + len(eyes) * n / 8
+    row = {"instances": n, "views": len(eyes), "ms_per_launch": ms, "instance_views_per_s": n * len(eyes) / (ms * 1e-3),
+           "commands_per_view": counts, "algorithmic_GBps": nbytes / (ms * 1e-3) / 1e9, "timing": stats(ev),
+           "wall_clock_ms_per_launch": float(np.median(wall)),
+           "note": "one launch: instance data read once, matrix + world box built once, per view plane test + compaction; no matrices "
+                   "written (the frame's mip_run writes them); bound by VALU issue, not HBM"}
+    doc, src = views_pmc(n)
+    if doc and doc["counters_per_launch"].get("SQ_INSTS_VALU"):
+        valu = doc["counters_per_launch"]["SQ_INSTS_VALU"]
+        row["roofline"] = {
+            "bound": "valu", "kernel": "mip_cull_views_kernel", "achieved": valu / (ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+            "unit": "wave-instructions/s", "frac": valu / (ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
+            "valu_wave_instructions_per_launch": valu, "kernel_ms": ms, "kernel_ms_under_pmc": doc["kernel_ns_under_pmc"] * 1e-6,
+            "traffic": doc.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": nbytes, "source": src,
+            "note": "SQ_INSTS_VALU per launch (committed PMC pass of this kernel source) / this run's launch time; peak = one wave64 f32 "
+                    "VALU instruction per 4 cycles per SIMD (the kernel's translation unit is built without the SLP vectoriser: no "
+                    "packed instructions)",
+        }
+    return row
 
 
 def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_rank):
@@ -722,7 +750,7 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
     guarded("triangle_cull_100k", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, not args.no_cpu_baseline))
     guarded("triangle_cull_100k_strips", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, False, ordering="strips"))
     guarded("light_draw_lists", lambda: light_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank))
-    guarded("culled_views_x4", lambda: views_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank))
+    guarded("culled_views_x4", lambda: views_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank, stream))
     guarded("skinned_256k", lambda: skinned_leg(torch, renderer_amd, scene, make_frame, None, device, local_rank))
 
 
