@@ -38,6 +38,10 @@ def random_skeleton(rng, j):
     ibm[:, [0, 5, 10]] = rng.uniform(0.8, 1.2, (j, 3))
     lo = rng.uniform(-1, 0, (j, 3)).astype(np.float32)
     box = np.concatenate([lo, lo + rng.uniform(-0.2, 1.0, (j, 3)).astype(np.float32)], axis=1)  # some boxes are empty
+    if rng.random() < 0.15:  # a joint box with a special value: the kernel's separable box fold must step aside (SkinArgs.box_bound)
+        box[rng.integers(0, j), rng.integers(0, 6)] = rng.choice(SPECIAL)
+    if rng.random() < 0.1:   # huge boxes: products overflow in some poses only
+        box *= np.float32(1e37)
     return dict(parent=parent, inverse_bind=ibm, joint_box=box)
 
 
