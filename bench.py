@@ -767,7 +767,10 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
     outs = DeviceOutputs(torch, n_local, device)
     frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=lo)
     torch.cuda.synchronize()
-    ex = DrawListExchange(pipe, n_local, world, rank, device, wire=os.environ.get("MIP_BENCH_WIRE", "1") != "0")  # 0: A/B against 20-byte commands
+    # MIP_BENCH_WIRE: A/B of the exchanged form — unset / 2: packed 4-byte records when the largest shard fits (else 8-byte),
+    # 1: 8-byte records, 0: 20-byte commands
+    wire_env = os.environ.get("MIP_BENCH_WIRE", "2")
+    ex = DrawListExchange(pipe, n_local, world, rank, device, wire={"0": False, "1": 1}.get(wire_env, True))
     timeouts = [0]
 
     def settle():
@@ -829,7 +832,9 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
             "emitted_fraction": float(counts.sum()) / max(n_total, 1),
             "draw_list_exchange": "rccl all-gather (torch.distributed nccl backend) + merge kernel, inside the timed region",
             "chunk_bytes_per_rank": int(ex.stride),
-            "chunk_format": "wire: 8-byte records {firstInstance, mesh | lod} in blocks of 256 (MIP_OUT_WIRE), expanded by the merge" if ex.wire else "20-byte commands",
+            "chunk_format": {0: "20-byte commands",
+                             1: "wire: 8-byte records {firstInstance, mesh | lod} in blocks of 256 (MIP_OUT_WIRE), expanded by the merge",
+                             2: "packed wire: 4-byte records {instance index | mesh | lod} in blocks of 256 (MIP_OUT_WIRE_PACKED), expanded by the merge"}[ex.form],
             "chunk_bytes_per_rank_as_20_byte_commands": int((32 + ex.capacity * 20 + 255) // 256 * 256),
             "chunk_capacity_commands": int(ex.capacity),
             "chunk_capacity_untightened": int(capacity_full),
@@ -848,9 +853,10 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
         k_ms = barrier_samples(torch, dist, lambda: pipe.run_device(frame, async_=True, **kw), args.steps, args.warmup, 10, True)
         pipe.wait()
         g_ms = barrier_samples(torch, dist, lambda: dist.all_gather_into_tensor(ex.recv, ex.send), args.steps, 3, 10, True)
-        merge_fn = pipe.merge_wire_lists if ex.wire else pipe.merge_draw_lists
+        merge_fn = pipe.merge_wire_lists if ex.form else pipe.merge_draw_lists
+        merge_kw = {"packed": True} if ex.form == 2 else {}
         m_ms = barrier_samples(torch, dist, lambda: merge_fn(ex.recv.data_ptr(), world, ex.stride, ex.merged.data_ptr(),
-                                                             ex.merged_count.data_ptr(), async_=True, chunk_capacity=ex.capacity),
+                                                             ex.merged_count.data_ptr(), async_=True, chunk_capacity=ex.capacity, **merge_kw),
                                args.steps, 3, 10, True)
         pipe.wait()
         result["breakdown_ms_per_step"] = {

@@ -75,6 +75,10 @@ extern "C" {
                               * command instead of 20) — what a rank sends through the all-gather; draw_count and
                               * draw_index_total as usual. Not with culled_index_buffer (the wire form carries no
                               * indexCount: it is the mesh table's). mip_merge_wire_lists expands it again. */
+#define MIP_OUT_WIRE_PACKED 0x8u /* with MIP_OUT_WIRE: the PACKED wire form below, 4.06 B per command — one 32-bit record
+                              * {instance index in the frame | mesh_id << index_bits | lod << 31}. Only while the
+                              * context's instance count fits: n <= 1 << mip_wire_index_bits(n_meshes), else
+                              * MIP_ERR_INVALID_ARGUMENT. mip_merge_wire_lists_packed expands it. */
 
 /* Largest LOD chain the scene loader can produce: LOD0 + 5 simplified levels
  * (src/renderer/systems/scene_loader.rs:740-753). */
@@ -220,6 +224,18 @@ typedef struct MipShardHeader {
 /* bytes of the body of a wire list with room for `capacity` commands (whole blocks) */
 #define MIP_WIRE_BODY_BYTES(capacity) \
   ((((uint64_t)(capacity) + MIP_WIRE_BLOCK_COMMANDS - 1u) / MIP_WIRE_BLOCK_COMMANDS) * MIP_WIRE_BLOCK_BYTES)
+/* The PACKED wire form (MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED): the same blocks with ONE 32-bit record per command,
+ *     instance_index | mesh_id << index_bits | lod << 31,      instance_index = firstInstance - first_instance_base,
+ * and a block header {firstIndex of the block's first command, the frame's first_instance_base, index_bits, 0}.
+ * index_bits = mip_wire_index_bits(n_meshes) = 31 - ceil(log2(n_meshes)) is what the mesh ids leave of the word, so the
+ * form exists for frames of at most 1 << index_bits instances (64 meshes: 33 M; 1 024 meshes: 2 M) — every rank of an
+ * exchange derives the same answer from the replicated mesh table and the largest shard. */
+#define MIP_WIRE_PACKED_RECORD_BYTES 4u
+#define MIP_WIRE_PACKED_BLOCK_BYTES (MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES) /* 1040 */
+#define MIP_WIRE_PACKED_BODY_BYTES(capacity) \
+  ((((uint64_t)(capacity) + MIP_WIRE_BLOCK_COMMANDS - 1u) / MIP_WIRE_BLOCK_COMMANDS) * MIP_WIRE_PACKED_BLOCK_BYTES)
+/* bits of a packed record left for the instance index by a mesh table of n_meshes entries (pure function) */
+uint32_t mip_wire_index_bits(uint32_t n_meshes);
 
 uint32_t mip_abi_version(void);
 
@@ -383,12 +399,18 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
 int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks,
                              uint64_t chunk_stride_bytes, uint32_t chunk_capacity, void* out_cmds,
                              uint32_t* out_count, int32_t async);
+/* ... and for chunks in the PACKED wire form (MIP_OUT_WIRE_PACKED; chunk_stride_bytes >= sizeof(MipShardHeader) +
+ * MIP_WIRE_PACKED_BODY_BYTES(chunk_capacity)). Each block header carries its own index_bits; one that cannot be (> 31)
+ * is a corrupt chunk and reported like a bad mesh id. */
+int32_t mip_merge_wire_lists_packed(MipContext* ctx, const void* chunks, uint32_t n_chunks,
+                                    uint64_t chunk_stride_bytes, uint32_t chunk_capacity, void* out_cmds,
+                                    uint32_t* out_count, int32_t async);
 
 /* ---- sharded scenes without a Python host: RCCL straight from the library ------------------
  * librccl.so.1 is opened with dlopen on first use, so single-GPU hosts do not need it. The
  * exchange is the one of SURVEY.md §8e: every rank runs its shard, ONE ncclAllGather moves the
- * fixed-size chunks [MipShardHeader | wire body for chunk_capacity commands: 8.06 B each instead of
- * 20, see MIP_OUT_WIRE], mip_merge_wire_lists' kernel expands and concatenates them. Needs a context with one frame in flight. */
+ * fixed-size chunks [MipShardHeader | wire body for chunk_capacity commands: 4.06 B each (packed form; 8.06 B when the
+ * largest shard does not fit a packed record) instead of 20, see MIP_OUT_WIRE], the merge kernel expands and concatenates them. Needs a context with one frame in flight. */
 #define MIP_COMM_ID_BYTES 128u
 
 /* ncclGetUniqueId: call on one rank, hand the 128 bytes to the others by any means. */

@@ -9,6 +9,7 @@ pub const MIP_OUT_HOST: u32 = 0;
 pub const MIP_OUT_DEVICE: u32 = 1;
 pub const MIP_OUT_ASYNC: u32 = 2;
 pub const MIP_OUT_WIRE: u32 = 4;
+pub const MIP_OUT_WIRE_PACKED: u32 = 8;
 pub const MIP_SEMAPHORE_BINARY: u32 = 0;
 pub const MIP_SEMAPHORE_TIMELINE: u32 = 1;
 pub const MIP_MAX_LODS: usize = 6;
@@ -118,6 +119,11 @@ extern "C" {
     /// The same merge over chunks in the wire form (MIP_OUT_WIRE: 8-byte records, expanded against the mesh table).
     pub fn mip_merge_wire_lists(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
                                 chunk_capacity: u32, out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+    /// ... and in the packed wire form (MIP_OUT_WIRE_PACKED: one 32-bit record per command).
+    pub fn mip_merge_wire_lists_packed(ctx: *mut MipContext, chunks: *const c_void, n_chunks: u32, chunk_stride_bytes: u64,
+                                       chunk_capacity: u32, out_cmds: *mut c_void, out_count: *mut u32, async_: i32) -> i32;
+    /// Bits of a packed record left for the instance index by a table of `n_meshes` entries.
+    pub fn mip_wire_index_bits(n_meshes: u32) -> u32;
     /// Shadow pass (shadow_mapping.rs:405-478): n_lights x n commands, light-major, into device memory.
     pub fn mip_light_draw_lists(ctx: *mut MipContext, light_pos_xyz: *const f32, n_lights: u32, first_instance_base: u32,
                                 out_cmds: *mut c_void, async_: i32) -> i32;

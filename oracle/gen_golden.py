@@ -98,14 +98,15 @@ def dump_wire(name, golden_name):
     """Extension fixture: the WIRE form (include/mi_instance_pipeline.h, MIP_OUT_WIRE) of a committed golden frame's draw
     list, from the numpy statement of the format in tests/cpu_pipeline.py — pins the byte layout the kernels speak."""
     sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
-    from cpu_pipeline import encode_wire
+    from cpu_pipeline import encode_wire, encode_wire_packed
 
     g = np.load(os.path.join(OUT, golden_name + ".npz"))
     cmds = g["draw_cmds"]
     inst = (cmds["firstInstance"] - np.uint32(g["first_instance_base"])).astype(np.int64)
     far = np.array([oracle.pick_lod(2, g["cam_pos"], g["pos"][i]) for i in inst], np.uint32)
     body = encode_wire(cmds, g["mesh_id"][inst], far)
-    np.savez_compressed(os.path.join(OUT, "ext", name + ".npz"), source=np.array(golden_name), body=body,
+    body_packed = encode_wire_packed(cmds, g["mesh_id"][inst], far, g["first_instance_base"], len(g["meshes"]))  # MIP_OUT_WIRE_PACKED
+    np.savez_compressed(os.path.join(OUT, "ext", name + ".npz"), source=np.array(golden_name), body=body, body_packed=body_packed,
                         draw_count=np.uint32(len(cmds)), draw_index_total=g["draw_index_total"])
     print(f"ext/{name}: {len(cmds)} commands -> {body.nbytes} wire bytes ({body.nbytes / max(len(cmds), 1):.2f} B per command)")
 

@@ -23,10 +23,13 @@ MIP_OUT_HOST = 0x0
 MIP_OUT_DEVICE = 0x1
 MIP_OUT_ASYNC = 0x2
 MIP_OUT_WIRE = 0x4
+MIP_OUT_WIRE_PACKED = 0x8
 MIP_WIRE_BLOCK_COMMANDS = 256
 MIP_WIRE_BLOCK_HEADER_BYTES = 16
 MIP_WIRE_RECORD_BYTES = 8
 MIP_WIRE_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_RECORD_BYTES
+MIP_WIRE_PACKED_RECORD_BYTES = 4
+MIP_WIRE_PACKED_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES
 MIP_MAX_LODS = 6
 MIP_SEMAPHORE_BINARY = 0
 MIP_SEMAPHORE_TIMELINE = 1
@@ -34,7 +37,7 @@ MIP_SEMAPHORE_TIMELINE = 1
 # Every symbol include/mi_instance_pipeline.h declares.
 EXPORTS = (
     "mip_abi_version", "mip_create", "mip_destroy", "mip_set_mesh_table", "mip_set_instances",
-    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_merge_wire_lists", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_import_external_semaphore_fd", "mip_external_semaphore_on_device", "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore", "mip_last_error",
+    "mip_set_instances_device", "mip_update_instances", "mip_set_geometry", "mip_set_blas_addresses", "mip_run", "mip_run_many", "mip_wait", "mip_merge_draw_lists", "mip_merge_wire_lists", "mip_merge_wire_lists_packed", "mip_wire_index_bits", "mip_light_draw_lists", "mip_set_skeleton", "mip_set_poses", "mip_run_skinned", "mip_run_views", "mip_comm_unique_id", "mip_comm_init", "mip_comm_destroy", "mip_run_sharded", "mip_import_external_fd", "mip_release_external", "mip_import_external_semaphore_fd", "mip_external_semaphore_on_device", "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore", "mip_last_error",
     "mip_get_timings", "mip_reset_timings", "mip_instance_count",
 )
 
@@ -119,7 +122,7 @@ def library_path():
     return _SO
 
 
-def _declare_newer(lib, name, argtypes):
+def _declare_newer(lib, name, argtypes, restype=C.c_int32):
     """Entry points added after ABI 2. The product library has them all (tests/test_abi.py); an older build loaded through
     MIP_LIBRARY for a same-box A/B (tools/kbench.py against a previous round's kernel) may not — only then is one skipped."""
     try:
@@ -129,7 +132,7 @@ def _declare_newer(lib, name, argtypes):
             return
         raise
     fn.argtypes = argtypes
-    fn.restype = C.c_int32
+    fn.restype = restype
 
 
 def load_library():
@@ -178,6 +181,8 @@ def load_library():
     lib.mip_merge_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32]
     lib.mip_merge_draw_lists.restype = C.c_int32
     _declare_newer(lib, "mip_merge_wire_lists", [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32])
+    _declare_newer(lib, "mip_merge_wire_lists_packed", [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, vp, C.c_int32])
+    _declare_newer(lib, "mip_wire_index_bits", [C.c_uint32], restype=C.c_uint32)
     lib.mip_light_draw_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_int32]
     lib.mip_light_draw_lists.restype = C.c_int32
     lib.mip_set_skeleton.argtypes = [vp, vp, vp, vp, C.c_uint32]

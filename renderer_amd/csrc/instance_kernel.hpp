@@ -98,6 +98,7 @@ struct KernelArgs {
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
   uint32_t bitmap_words;
   uint32_t n_meshes;            // mesh-table entries
+  uint32_t wire_index_bits;     // MIP_OUT_WIRE_PACKED: bits of a record that hold the instance index (mesh id above them, LOD in bit 31)
   // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
   // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
   // without re-recording: the host refreshes the ring with one copy per replay
@@ -607,6 +608,7 @@ static __global__ __launch_bounds__(256) __attribute__((unused)) void mip_count_
 // block's first command. 8.06 B per command instead of 20 through the all-gather; mip_merge_wire_lists_kernel
 // (merge_kernel.hpp) expands it against the replicated mesh table.
 constexpr uint32_t kWireBlockCmds = 256, kWireBlockHeaderWords = 4, kWireBlockWords = kWireBlockHeaderWords + 2 * kWireBlockCmds;
+constexpr uint32_t kWirePackedBlockWords = kWireBlockHeaderWords + kWireBlockCmds;  // MIP_OUT_WIRE_PACKED: one word per record
 
 // Copy-out of a tile's `tile_count` staged commands (LDS, kCmdLdsWords each: [2] tile-relative firstIndex,
 // [4] firstInstance, [5] mesh | lod << 31) as wire records at list positions base_count .. ; run by one wave.
@@ -618,6 +620,20 @@ __device__ __forceinline__ void wire_copy_out(uint32_t* body, const uint32_t* s_
     const uint32_t* c = &s_cmd[k * kCmdLdsWords];
     *reinterpret_cast<uint2*>(b + kWireBlockHeaderWords + 2u * slot) = make_uint2(c[4], c[5]);
     if (slot == 0u) *reinterpret_cast<uint4*>(b) = make_uint4(c[2] + first_index_add, 0u, 0u, 0u);
+  }
+}
+
+// The same for the PACKED wire form (MIP_OUT_WIRE_PACKED): one word per command,
+// instance index in the frame | mesh << index_bits | lod << 31; block header {firstIndex, first_instance_base, index_bits, 0}.
+__device__ __forceinline__ void wire_packed_copy_out(uint32_t* body, const uint32_t* s_cmd, uint32_t lane, uint32_t base_count,
+                                                     uint32_t first_index_add, uint32_t tile_count, uint32_t first_instance_base,
+                                                     uint32_t index_bits) {
+  for (uint32_t k = lane; k < tile_count; k += 64u) {
+    const uint32_t g = base_count + k, block = g / kWireBlockCmds, slot = g % kWireBlockCmds;
+    uint32_t* b = body + (size_t)block * kWirePackedBlockWords;
+    const uint32_t* c = &s_cmd[k * kCmdLdsWords];
+    b[kWireBlockHeaderWords + slot] = (c[4] - first_instance_base) | ((c[5] & 0x7fffffffu) << index_bits) | (c[5] & 0x80000000u);
+    if (slot == 0u) *reinterpret_cast<uint4*>(b) = make_uint4(c[2] + first_index_add, first_instance_base, index_bits, 0u);
   }
 }
 
@@ -647,9 +663,10 @@ constexpr uint32_t kAggArrivalShift = 24;
 //      matrix pieces while wave 0 spends that time on the prefix round trip and the copy-out.
 //      Shortest dependency chain per tile; best while every tile is in the launch's first and last
 //      generation of workgroups (100 k instances: 6.1 vs 6.9 us).
-// kWire: the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above). A template
+// kWire: 1 = the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above), 2 = in its
+// packed form (MIP_OUT_WIRE_PACKED, wire_packed_copy_out; KernelArgs.wire_index_bits); 0 = 20-byte commands. A template
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
-template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder, bool kWire = false>
+template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0>
 __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
   static_assert(kOrder == 1 || kOrder == 3, "unknown order");
   static_assert(!kWire || !kBoxOverride, "skinned frames do not emit the wire form");
@@ -920,7 +937,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     MIP_STAMP(4);
     const uint32_t first_index_add = base_sum + first_index_base;
     if constexpr (kWire) {
-      wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
+      if constexpr (kWire == 2) wire_packed_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count, first_instance_base, a.wire_index_bits);
+      else wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
       store_aabb();
       MIP_STAMP(5);
       return;
@@ -1017,7 +1035,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // ---- coalesced copy-out of the tile's commands ----
   const uint32_t first_index_add = base_sum + first_index_base;
   if constexpr (kWire) {
-    wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
+    if constexpr (kWire == 2) wire_packed_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count, first_instance_base, a.wire_index_bits);
+    else wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
     store_aabb();
     MIP_STAMP(5);
     return;

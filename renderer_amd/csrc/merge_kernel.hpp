@@ -86,15 +86,19 @@ struct MergeWireArgs {
   uint32_t n_meshes;
 };
 
+// kPacked: the chunks are in the packed wire form (MIP_OUT_WIRE_PACKED): one 32-bit record per command,
+// instance index | mesh << index_bits | lod << 31, block header {firstIndex, first_instance_base, index_bits, 0}.
+template <bool kPacked>
 __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWireArgs a) {
   static_assert(kWireBlockCmds == 256, "one thread per record of a block");
+  constexpr uint32_t kBlockWords = kPacked ? kWirePackedBlockWords : kWireBlockWords;
   __shared__ uint32_t s_count_base[kMaxMergeChunks + 1], s_index_base[kMaxMergeChunks + 1], s_block_base[kMaxMergeChunks + 1];
   __shared__ uint32_t s_wave_total[4];
   __shared__ uint32_t s_out[kWireBlockCmds * kCmdWords];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // chunk tables: lane k of wave 0 reads header k (one round trip for all <= 64 chunks, not one per chunk), three wave scans
   if (wave == 0) {
-    const uint32_t fits = (uint32_t)((a.stride - 32u) / (kWireBlockWords * 4u)) * kWireBlockCmds;
+    const uint32_t fits = (uint32_t)((a.stride - 32u) / (kBlockWords * 4u)) * kWireBlockCmds;
     const uint32_t capacity = a.capacity < fits ? a.capacity : fits;
     uint32_t count = 0, total = 0;
     if (lane < a.n_chunks) {
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
     b = blk - s_block_base[chunk];
     const uint32_t chunk_count = s_count_base[chunk + 1] - s_count_base[chunk];
     in_block = chunk_count - b * kWireBlockCmds < kWireBlockCmds ? chunk_count - b * kWireBlockCmds : kWireBlockCmds;
-    body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kWireBlockWords;
+    body = reinterpret_cast<const uint32_t*>(a.chunks + chunk * a.stride + 32) + (size_t)b * kBlockWords;
   };
   // Software pipeline, two deep: while block i is expanded, the table entries of block i + 1 (gathers that depend on its
   // records) and the records + header of block i + 2 are in flight.
@@ -143,8 +147,24 @@ __global__ __launch_bounds__(256) void mip_merge_wire_lists_kernel(const MergeWi
     if (blk < total_blocks) {
       locate(blk, l.b, l.in_block, body);
       l.chunk = chunk;
-      if (tid < l.in_block) l.rec = *reinterpret_cast<const uint2*>(body + kWireBlockHeaderWords + 2u * tid);
-      l.first_index = body[0];
+      if constexpr (kPacked) {
+        // the record's words, unpacked: {firstInstance, mesh | lod << 31} as the 8-byte form carries them
+        const uint4 h = *reinterpret_cast<const uint4*>(body);  // wave-uniform address
+        uint32_t bits = h.z;
+        if (bits > 31u) {  // a corrupt header must not become an undefined shift
+          if (tid == 0) raise_error(a.error_flag, kErrWireRecord);
+          bits = 31u;
+        }
+        if (tid < l.in_block) {
+          const uint32_t r = body[kWireBlockHeaderWords + tid];
+          const uint32_t low = r & 0x7fffffffu;
+          l.rec = make_uint2(h.y + (low & ((1u << bits) - 1u)), (low >> bits) | (r & 0x80000000u));
+        }
+        l.first_index = h.x;
+      } else {
+        if (tid < l.in_block) l.rec = *reinterpret_cast<const uint2*>(body + kWireBlockHeaderWords + 2u * tid);
+        l.first_index = body[0];
+      }
     }
   };
   auto fetch_table = [&](const Located& l, uint32_t& len, int32_t& vertex_offset) {

@@ -149,7 +149,9 @@ struct MipContext {
   ncclComm_t comm = nullptr;
   uint32_t comm_rank = 0, comm_world = 0;
   uint32_t shard_cap_max = 0;  // largest max_instances over the ranks: what every rank sizes its chunks by
-  bool shard_wire = true;      // mip_run_sharded exchanges the wire form of the lists (MIP_TUNE_SHARD_WIRE=0: 20-byte commands)
+  int shard_wire = 2;          // what mip_run_sharded exchanges: 2 = the packed wire form whenever the largest shard fits it (else 1),
+                               // 1 = 8-byte wire records, 0 = 20-byte commands (MIP_TUNE_SHARD_WIRE: A/B and tests)
+  int sharded_form = 0;        // the form of the frame in flight (what the send buffer holds; repair_sharded_overflow re-sends it)
   uint32_t* d_send = nullptr;  // this rank's chunk, sized for max_instances commands
   uint32_t* d_recv = nullptr;  // world chunks
   // the last sharded frame, kept so that a tightened chunk that overflowed can be re-gathered at full capacity
@@ -307,13 +309,14 @@ const RcclApi* rccl() {
 using FrameKernel = mip::FrameKernelFn;
 // the stores-first order (kOrder == 1) is instantiated here; the commands-first order (3) in stages_tu.hip, built with
 // other flags — never both in one unit (stage_args.hpp)
-template <bool kBox, bool kGeneral, bool kWire>
+template <bool kBox, bool kGeneral, int kWire>
 FrameKernel pick_order(bool ticketed, int order) {
   if (order != 1) return mip::frame_kernel_commands_first(ticketed, kBox, kGeneral, kWire);
   return ticketed ? (FrameKernel)mip::mip_instance_pipeline_kernel<true, kBox, kGeneral, 1, kWire>
                   : (FrameKernel)mip::mip_instance_pipeline_kernel<false, kBox, kGeneral, 1, kWire>;
 }
-FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool wire, uint32_t* grid) {
+int wire_form(uint32_t out_flags) { return (out_flags & MIP_OUT_WIRE) ? ((out_flags & MIP_OUT_WIRE_PACKED) ? 2 : 1) : 0; }
+FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, int wire /* 0 | 1 | 2 = packed */, uint32_t* grid) {
   const uint32_t n_tiles = tiles_for(ctx->n);
   *grid = n_tiles;
   // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of
@@ -323,10 +326,11 @@ FrameKernel select_frame_kernel(const MipContext* ctx, bool box_override, bool w
   // (2 M: 34.1 vs 35.7; 4 M: 64.4 vs 68; 10 M: 181 vs 232 us; 1 M: equal within the run-to-run spread).
   int order = n_tiles <= (uint32_t)ctx->cu_count * 14u ? 3 : 1;
   if (ctx->force_order) order = ctx->force_order;
-  if (box_override) return pick_order<true, true, false>(ctx->ordered_tiles, order);  // (validate_run refuses MIP_OUT_WIRE for skinned frames)
+  if (box_override) return pick_order<true, true, 0>(ctx->ordered_tiles, order);  // (validate_run refuses MIP_OUT_WIRE for skinned frames)
   const bool general = ctx->nonfinite_instances != 0 || ctx->force_general;
-  if (wire) return general ? pick_order<false, true, true>(ctx->ordered_tiles, order) : pick_order<false, false, true>(ctx->ordered_tiles, order);
-  return general ? pick_order<false, true, false>(ctx->ordered_tiles, order) : pick_order<false, false, false>(ctx->ordered_tiles, order);
+  if (wire == 2) return general ? pick_order<false, true, 2>(ctx->ordered_tiles, order) : pick_order<false, false, 2>(ctx->ordered_tiles, order);
+  if (wire == 1) return general ? pick_order<false, true, 1>(ctx->ordered_tiles, order) : pick_order<false, false, 1>(ctx->ordered_tiles, order);
+  return general ? pick_order<false, true, 0>(ctx->ordered_tiles, order) : pick_order<false, false, 0>(ctx->ordered_tiles, order);
 }
 
 // Number of instances of [first, first + count) of the resident columns that fail the finite test, and (bad_ids != null)
@@ -380,6 +384,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
+  a.wire_index_bits = mip_wire_index_bits(ctx->m);
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;
   std::memcpy(a.planes, frame->planes, sizeof a.planes);
@@ -457,6 +462,11 @@ int32_t validate_run(MipContext* ctx, const MipFrame* frame, const MipOutputs* o
     if (!device_out || !out->draw_cmds) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs MIP_OUT_DEVICE and draw_cmds");
     if (out->culled_index_buffer) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE cannot carry the per-triangle stage's indexCount");
     if (ctx->m > 0x7fffffffu) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs mesh ids below 2^31");
+    if ((out->flags & MIP_OUT_WIRE_PACKED) && (uint64_t)ctx->n > (1ull << mip_wire_index_bits(ctx->m)))
+      return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE_PACKED: %u instances do not fit the %u index bits a table of %u meshes leaves",
+                  ctx->n, mip_wire_index_bits(ctx->m), ctx->m);
+  } else if (out->flags & MIP_OUT_WIRE_PACKED) {
+    return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE_PACKED goes with MIP_OUT_WIRE");
   }
   if (out->culled_index_buffer) {
     if (!device_out) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
@@ -938,7 +948,7 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       void* params[1] = {&a};
       if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
       uint32_t grid = 0;
-      const FrameKernel kernel = select_frame_kernel(ctx, skinned, device_out && (out->flags & MIP_OUT_WIRE) != 0, &grid);
+      const FrameKernel kernel = select_frame_kernel(ctx, skinned, device_out ? wire_form(out->flags) : 0, &grid);
       MIP_HIP(ctx, hipLaunchKernel((const void*)kernel, dim3(grid), dim3(mip::kTile), params, ctx->lds_pad, stream));
     }
     if (triangles) {
@@ -1161,7 +1171,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           void* params[1] = {&a};
           hipKernelNodeParams kp{};
           uint32_t grid = 0;
-          kp.func = (void*)select_frame_kernel(ctx, false, (out->flags & MIP_OUT_WIRE) != 0, &grid);
+          kp.func = (void*)select_frame_kernel(ctx, false, wire_form(out->flags), &grid);
           kp.gridDim = dim3(grid);
           kp.blockDim = dim3(mip::kTile);
           kp.sharedMemBytes = ctx->lds_pad;
@@ -1555,14 +1565,18 @@ int32_t mip_merge_draw_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
   return check_device_error(ctx);
 }
 
-static uint64_t wire_stride_bytes(uint64_t capacity) {
-  return (sizeof(MipShardHeader) + MIP_WIRE_BODY_BYTES(capacity) + 255) / 256 * 256;
+static uint64_t wire_body_bytes(uint64_t capacity, bool packed) {
+  return packed ? MIP_WIRE_PACKED_BODY_BYTES(capacity) : MIP_WIRE_BODY_BYTES(capacity);
+}
+static uint64_t wire_stride_bytes(uint64_t capacity, bool packed) {
+  return (sizeof(MipShardHeader) + wire_body_bytes(capacity, packed) + 255) / 256 * 256;
 }
 
 static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
-                                  uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count) {
+                                  uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, bool packed) {
   static_assert(MIP_WIRE_BLOCK_COMMANDS == mip::kWireBlockCmds && MIP_WIRE_BLOCK_BYTES == mip::kWireBlockWords * 4u &&
-                MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u, "wire layout: header and kernels agree");
+                MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u && MIP_WIRE_PACKED_BLOCK_BYTES == mip::kWirePackedBlockWords * 4u,
+                "wire layout: header and kernels agree");
   mip::MergeWireArgs a{};
   a.chunks = (const unsigned char*)chunks;
   a.stride = chunk_stride_bytes;
@@ -1579,13 +1593,14 @@ static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t 
   const uint32_t grid_cap = std::getenv("MIP_TUNE_MERGE_GRID") ? (uint32_t)std::atoi(std::getenv("MIP_TUNE_MERGE_GRID")) : 256u * 8u;
   uint32_t blocks = max_blocks > grid_cap ? grid_cap : (uint32_t)max_blocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mip::mip_merge_wire_lists_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+  if (packed) hipLaunchKernelGGL(mip::mip_merge_wire_lists_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(mip::mip_merge_wire_lists_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, a);
   MIP_HIP(ctx, hipGetLastError());
   return MIP_OK;
 }
 
-int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
-                             uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async) {
+static int32_t merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                                uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async, bool packed) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!chunks || !out_cmds || !out_count) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL pointer");
   if (!ctx->have_meshes) return fail(ctx, MIP_ERR_NOT_READY, "wire records are expanded against the mesh table: set it first");
@@ -1593,16 +1608,16 @@ int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "n_chunks %u outside 1..%u", n_chunks, mip::kMaxMergeChunks);
   if (chunk_stride_bytes < sizeof(MipShardHeader)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "bad chunk stride");
   if (chunk_capacity == 0) {  // what the stride holds, in whole blocks
-    const uint64_t fits = (chunk_stride_bytes - sizeof(MipShardHeader)) / MIP_WIRE_BLOCK_BYTES * MIP_WIRE_BLOCK_COMMANDS;
+    const uint64_t fits = (chunk_stride_bytes - sizeof(MipShardHeader)) / (packed ? MIP_WIRE_PACKED_BLOCK_BYTES : MIP_WIRE_BLOCK_BYTES) * MIP_WIRE_BLOCK_COMMANDS;
     chunk_capacity = fits > 0x3fffffffull ? 0x3fffffffu : (uint32_t)fits;
   }
-  if ((chunk_stride_bytes & 15u) || sizeof(MipShardHeader) + MIP_WIRE_BODY_BYTES(chunk_capacity) > chunk_stride_bytes)
+  if ((chunk_stride_bytes & 15u) || sizeof(MipShardHeader) + wire_body_bytes(chunk_capacity, packed) > chunk_stride_bytes)
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "a wire chunk for %u commands does not fit a stride of %llu bytes (or the stride is not 16-byte aligned)",
                 chunk_capacity, (unsigned long long)chunk_stride_bytes);
   if (int32_t rc = bind_device(ctx)) return rc;
   const bool timing = (ctx->cfg_flags & MIP_CFG_TIMING) != 0 && !async;
   if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  if (int32_t rc = enqueue_merge_wire(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count)) return rc;
+  if (int32_t rc = enqueue_merge_wire(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count, packed)) return rc;
   if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (async) {
     ctx->pending_async = true;
@@ -1617,6 +1632,22 @@ int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chu
     ctx->timings.total_merge_ms += ms;
   }
   return check_device_error(ctx);
+}
+
+int32_t mip_merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                             uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async) {
+  return merge_wire_lists(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count, async, false);
+}
+
+int32_t mip_merge_wire_lists_packed(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
+                                    uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, int32_t async) {
+  return merge_wire_lists(ctx, chunks, n_chunks, chunk_stride_bytes, chunk_capacity, out_cmds, out_count, async, true);
+}
+
+uint32_t mip_wire_index_bits(uint32_t n_meshes) {
+  uint32_t mesh_bits = 0;
+  while (mesh_bits < 31u && (1ull << mesh_bits) < n_meshes) ++mesh_bits;  // ceil(log2(n_meshes)); 0 for one mesh
+  return 31u - mesh_bits;
 }
 
 int32_t mip_comm_unique_id(uint8_t out_id[MIP_COMM_ID_BYTES]) {
@@ -1651,7 +1682,10 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
   }
   ctx->comm_rank = rank;
   ctx->comm_world = world;
-  if (const char* env = std::getenv("MIP_TUNE_SHARD_WIRE")) ctx->shard_wire = std::atoi(env) != 0;  // A/B and tests: 0 = exchange 20-byte commands
+  if (const char* env = std::getenv("MIP_TUNE_SHARD_WIRE")) {  // A/B and tests: 0 = 20-byte commands, 1 = 8-byte records, 2 = packed when possible
+    const int v = std::atoi(env);
+    ctx->shard_wire = v < 0 ? 0 : (v > 2 ? 2 : v);
+  }
   const int32_t rc = [&]() -> int32_t {
     // Chunks must have the same size on every rank, but ranks may have been created for different capacities (the
     // last of ceil(N/R)-sized shards is shorter): one 4-byte all-gather settles on the largest max_instances.
@@ -1673,7 +1707,7 @@ int32_t mip_comm_init(MipContext* ctx, const uint8_t id[MIP_COMM_ID_BYTES], uint
     for (uint32_t c : caps) ctx->shard_cap_max = c > ctx->shard_cap_max ? c : ctx->shard_cap_max;
     const size_t cap = ctx->shard_cap_max;
     size_t stride = (sizeof(MipShardHeader) + cap * 20 + 255) / 256 * 256;  // room for either form of the list
-    if (wire_stride_bytes(cap) > stride) stride = wire_stride_bytes(cap);
+    if (wire_stride_bytes(cap, false) > stride) stride = wire_stride_bytes(cap, false);
     MIP_HIP(ctx, hipMalloc(&ctx->d_send, stride));
     MIP_HIP(ctx, hipMemsetAsync(ctx->d_send, 0, stride, ctx->stream));
     MIP_HIP(ctx, hipMalloc(&ctx->d_recv, stride * world));
@@ -1699,12 +1733,13 @@ int32_t mip_comm_destroy(MipContext* ctx) {
 }
 
 static int32_t sharded_gather_and_merge(MipContext* ctx, uint32_t cap, void* out_cmds, uint32_t* out_count) {
-  if (ctx->shard_wire) {  // the list travels as 8-byte records (MIP_OUT_WIRE) and is expanded by the merge
-    const uint64_t stride = wire_stride_bytes(cap);
+  if (ctx->sharded_form) {  // the list travels as 8-byte or packed 4-byte records (MIP_OUT_WIRE) and is expanded by the merge
+    const bool packed = ctx->sharded_form == 2;
+    const uint64_t stride = wire_stride_bytes(cap, packed);
     const ncclResult_t res = rccl()->all_gather(ctx->d_send, ctx->d_recv, stride / 4, ncclUint32, ctx->comm, ctx->stream);
     if (res != ncclSuccess) return fail(ctx, MIP_ERR_DEVICE, "ncclAllGather failed: %s", rccl()->get_error_string ? rccl()->get_error_string(res) : "?");
     ctx->timings.sharded_bytes_sent = stride;
-    return enqueue_merge_wire(ctx, ctx->d_recv, ctx->comm_world, stride, cap, out_cmds, out_count);
+    return enqueue_merge_wire(ctx, ctx->d_recv, ctx->comm_world, stride, cap, out_cmds, out_count, packed);
   }
   const uint64_t stride = (sizeof(MipShardHeader) + (uint64_t)cap * 20 + 255) / 256 * 256;
   ctx->timings.sharded_bytes_sent = stride;
@@ -1729,7 +1764,11 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   local.draw_count = ctx->d_send;
   local.draw_index_total = ctx->d_send + 1;
   local.draw_cmds = ctx->d_send + sizeof(MipShardHeader) / 4;
-  local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC | (ctx->shard_wire ? MIP_OUT_WIRE : 0u);
+  // every rank takes the same form: the mesh table is replicated and shard_cap_max was all-gathered
+  int form = ctx->shard_wire;
+  if (form == 2 && (uint64_t)cap_max > (1ull << mip_wire_index_bits(ctx->m))) form = 1;
+  ctx->sharded_form = form;
+  local.flags = MIP_OUT_DEVICE | MIP_OUT_ASYNC | (form ? MIP_OUT_WIRE : 0u) | (form == 2 ? MIP_OUT_WIRE_PACKED : 0u);
   // kernel, all-gather and merge are ordered by ONE stream and share one send/receive buffer: a sharded
   // frame always takes frame slot 0 (= ctx->stream), whatever frames_in_flight is. Overlapping sharded
   // frames is done with several contexts (renderer_amd/sharded.py, PipelinedExchange).

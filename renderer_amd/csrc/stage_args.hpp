@@ -162,7 +162,7 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // ---- rows a-1 .. a-7, commands-first order (kOrder == 3 of instance_kernel.hpp: launches below ~0.9 M instances) ----
 // The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in mip_api.hip.
 using FrameKernelFn = void (*)(const KernelArgs);
-FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, bool wire);
+FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */);
 // first of the three wait-free launches of a large ordered-tiles frame (mip_tile_aggregate_kernel, instance_kernel.hpp)
 void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a);
 

@@ -49,17 +49,18 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // Every kOrder == 3 instantiation of the frame kernel lives here and only here (mip_api.hip instantiates kOrder == 1):
 // an instantiation referenced from both units would be registered twice under one host stub.
 namespace {
-template <bool kBox, bool kGeneral, bool kWire>
+template <bool kBox, bool kGeneral, int kWire>
 FrameKernelFn commands_first(bool ticketed) {
   return ticketed ? (FrameKernelFn)mip_instance_pipeline_kernel<true, kBox, kGeneral, 3, kWire>
                   : (FrameKernelFn)mip_instance_pipeline_kernel<false, kBox, kGeneral, 3, kWire>;
 }
 }  // namespace
 
-FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, bool wire) {
-  if (box_override) return commands_first<true, true, false>(ticketed);  // skinned frames: always general, never wire
-  if (wire) return general ? commands_first<false, true, true>(ticketed) : commands_first<false, false, true>(ticketed);
-  return general ? commands_first<false, true, false>(ticketed) : commands_first<false, false, false>(ticketed);
+FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, int wire) {
+  if (box_override) return commands_first<true, true, 0>(ticketed);  // skinned frames: always general, never wire
+  if (wire == 2) return general ? commands_first<false, true, 2>(ticketed) : commands_first<false, false, 2>(ticketed);
+  if (wire == 1) return general ? commands_first<false, true, 1>(ticketed) : commands_first<false, false, 1>(ticketed);
+  return general ? commands_first<false, true, 0>(ticketed) : commands_first<false, false, 0>(ticketed);
 }
 
 void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a) {

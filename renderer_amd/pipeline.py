@@ -30,10 +30,27 @@ DRAW_CMD_DTYPE = np.dtype(
 SHARD_HEADER_BYTES = 32
 
 
-def wire_body_bytes(capacity):
-    """MIP_WIRE_BODY_BYTES: whole blocks of 256 8-byte records behind a 16-byte block header."""
+def wire_form(wire):
+    """0 = 20-byte commands, 1 = 8-byte wire records (MIP_OUT_WIRE), 2 = packed 4-byte records (MIP_OUT_WIRE_PACKED).
+    Accepts False / True / 1 / 2 / "packed"."""
+    if wire in (2, "packed"):
+        return 2
+    return 1 if wire else 0
+
+
+def wire_index_bits(n_meshes):
+    """mip_wire_index_bits: what a table of n_meshes entries leaves of a packed record for the instance index."""
+    mesh_bits = 0
+    while mesh_bits < 31 and (1 << mesh_bits) < int(n_meshes):
+        mesh_bits += 1
+    return 31 - mesh_bits
+
+
+def wire_body_bytes(capacity, packed=False):
+    """MIP_WIRE_BODY_BYTES / MIP_WIRE_PACKED_BODY_BYTES: whole blocks of 256 records (8 bytes each, 4 in the packed form)
+    behind a 16-byte block header."""
     blocks = (int(capacity) + _lib.MIP_WIRE_BLOCK_COMMANDS - 1) // _lib.MIP_WIRE_BLOCK_COMMANDS
-    return blocks * _lib.MIP_WIRE_BLOCK_BYTES
+    return blocks * (_lib.MIP_WIRE_PACKED_BLOCK_BYTES if packed else _lib.MIP_WIRE_BLOCK_BYTES)
 
 
 def make_frame(planes, cam_pos, first_instance_base=0, first_index_base=0, pv=None):
@@ -99,6 +116,7 @@ class InstancePipeline:
     def set_mesh_table(self, meshes):
         meshes = np.ascontiguousarray(meshes, dtype=MESH_DTYPE).reshape(-1)
         self._check(self._lib.mip_set_mesh_table(self._ctx, meshes.ctypes.data, len(meshes)))
+        self.n_meshes = len(meshes)
 
     def set_instances(self, pos_xyz, rot_ijkw, scale, mesh_id):
         pos = np.ascontiguousarray(pos_xyz, dtype=np.float32).reshape(-1, 3)
@@ -179,9 +197,11 @@ class InstancePipeline:
                    draw_index_total=0, world_aabb=0, async_=False, culled_index_buffer=0, culled_index_capacity=0,
                    tlas_instances=0, wire=False):
         """Device pointers in, nothing copied. `frame` from make_frame(). wire=True: draw_cmds receives the
-        wire form of the list (MIP_OUT_WIRE)."""
+        wire form of the list (MIP_OUT_WIRE); wire="packed" (or 2): its packed form (MIP_OUT_WIRE_PACKED)."""
         out = MipOutputs()
-        out.flags = _lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0) | (_lib.MIP_OUT_WIRE if wire else 0)
+        form = wire_form(wire)
+        out.flags = (_lib.MIP_OUT_DEVICE | (_lib.MIP_OUT_ASYNC if async_ else 0) | (_lib.MIP_OUT_WIRE if form else 0)
+                     | (_lib.MIP_OUT_WIRE_PACKED if form == 2 else 0))
         out.model = model or None
         out.visible_bitmap = visible_bitmap or None
         out.draw_cmds = draw_cmds or None
@@ -315,11 +335,12 @@ class InstancePipeline:
                                                    out_count_ptr, 1 if async_ else 0))
 
     def merge_wire_lists(self, chunks_ptr, n_chunks, chunk_stride_bytes, out_cmds_ptr, out_count_ptr,
-                         async_=False, chunk_capacity=0):
-        """The same merge over chunks in the wire form (MIP_OUT_WIRE), expanded against this context's mesh table."""
-        self._check(self._lib.mip_merge_wire_lists(self._ctx, chunks_ptr, int(n_chunks),
-                                                   int(chunk_stride_bytes), int(chunk_capacity), out_cmds_ptr,
-                                                   out_count_ptr, 1 if async_ else 0))
+                         async_=False, chunk_capacity=0, packed=False):
+        """The same merge over chunks in the wire form (MIP_OUT_WIRE; packed=True: MIP_OUT_WIRE_PACKED), expanded against
+        this context's mesh table."""
+        fn = self._lib.mip_merge_wire_lists_packed if packed else self._lib.mip_merge_wire_lists
+        self._check(fn(self._ctx, chunks_ptr, int(n_chunks), int(chunk_stride_bytes), int(chunk_capacity), out_cmds_ptr,
+                       out_count_ptr, 1 if async_ else 0))
 
     # -- extension: skinned instances (BASELINE config 5; not a reference behaviour) --
     def set_skeleton(self, parent, inverse_bind, joint_box):

@@ -3,9 +3,11 @@ the compacted draw lists (torch.distributed: backend "nccl" = RCCL over xGMI on 
 "gloo" in the CPU tests) followed by a merge that concatenates the shards in rank order and
 rebases firstIndex.
 
-Every rank contributes one fixed-size chunk [MipShardHeader | the list in its WIRE form: 8-byte
-records {firstInstance, mesh | lod << 31} in blocks of 256 behind a 16-byte block header, 8.06 B
-per command instead of 20 — include/mi_instance_pipeline.h, MIP_OUT_WIRE]; the pipeline kernel
+Every rank contributes one fixed-size chunk [MipShardHeader | the list in its WIRE form: records
+in blocks of 256 behind a 16-byte block header — packed 4-byte records {instance index | mesh <<
+index_bits | lod << 31}, 4.06 B per command instead of 20, whenever the largest shard fits the index
+bits the mesh ids leave (MIP_OUT_WIRE_PACKED), else 8-byte records {firstInstance, mesh | lod << 31}
+(MIP_OUT_WIRE) — include/mi_instance_pipeline.h]; the pipeline kernel
 writes count / index total / records straight into that chunk and the merge kernel expands the
 records against the replicated mesh table, so a frame is kernel -> all_gather_into_tensor ->
 merge kernel with no host round trip. (`wire=False` exchanges the 20-byte commands themselves:
@@ -22,7 +24,7 @@ with world sizes 2 and 3 under gloo on CPU; N = 2/4/8 numbers come from the roun
 import numpy as np
 
 from ._lib import MipError
-from .pipeline import SHARD_HEADER_BYTES, make_frame, wire_body_bytes
+from .pipeline import SHARD_HEADER_BYTES, make_frame, wire_body_bytes, wire_form, wire_index_bits
 
 MIP_ERR_CAPACITY = -4
 
@@ -39,7 +41,9 @@ def shard_range(n_global, world, rank):
 
 
 def chunk_stride_bytes(capacity, wire=False):
-    stride = SHARD_HEADER_BYTES + (wire_body_bytes(capacity) if wire else capacity * CMD_BYTES)
+    """wire: False = 20-byte commands, True / 1 = 8-byte wire records, "packed" / 2 = packed 4-byte records."""
+    form = wire_form(wire)
+    stride = SHARD_HEADER_BYTES + (wire_body_bytes(capacity, packed=form == 2) if form else capacity * CMD_BYTES)
     return (stride + 255) // 256 * 256
 
 
@@ -50,7 +54,11 @@ class DrawListExchange:
     renderer_amd.InstancePipeline (the HIP context in the product; the tests inject a
     CPU stand-in so the exchange logic runs under gloo)."""
 
-    def __init__(self, pipe, n_local, world, rank, device, dist=None, torch=None, group=None, capacity=None, wire=True):
+    def __init__(self, pipe, n_local, world, rank, device, dist=None, torch=None, group=None, capacity=None, wire=True,
+                 n_meshes=None):
+        """wire: True = the wire form, PACKED when the largest shard fits the index bits a table of `n_meshes` entries
+        leaves (n_meshes defaults to pipe.n_meshes; unknown: 8-byte records); 1 = 8-byte records; "packed" = packed or
+        an error; False = 20-byte commands. Every rank must pass the same value — and holds the same mesh table."""
         if torch is None:
             import torch
         if dist is None:
@@ -66,8 +74,18 @@ class DrawListExchange:
         if self.world > 1:
             dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
         self.n_max = int(nmax.item())
+        # the form of the list: derived from numbers every rank has (the largest shard, the replicated table's size)
+        if n_meshes is None:
+            n_meshes = getattr(pipe, "n_meshes", None)
+        fits = n_meshes is not None and self.n_max <= (1 << wire_index_bits(n_meshes))
+        if wire is True:
+            self.form = 2 if fits else 1
+        else:
+            self.form = wire_form(wire)
+            if self.form == 2 and not fits:
+                raise ValueError(f"packed wire records: shards of up to {self.n_max} instances do not fit beside {n_meshes} mesh ids")
         # the kernel may emit up to n_local commands, so the send buffer always has room for all of them
-        self._send_full = torch.zeros(chunk_stride_bytes(self.n_max, self.wire) // 4, dtype=torch.int32, device=device)
+        self._send_full = torch.zeros(chunk_stride_bytes(self.n_max, self.form) // 4, dtype=torch.int32, device=device)
         self.merged_count = torch.zeros(2, dtype=torch.int32, device=device)
         self.retries = 0       # frames re-gathered at full capacity after a tightened chunk overflowed
         self._in_flight = 0    # frames issued since the last complete()
@@ -76,7 +94,7 @@ class DrawListExchange:
     def set_capacity(self, capacity):
         torch = self.torch
         self.capacity = int(min(max(capacity, 0), self.n_max))  # the same number on every rank
-        self.stride = chunk_stride_bytes(self.capacity, self.wire)
+        self.stride = chunk_stride_bytes(self.capacity, self.form)
         words = self.stride // 4
         self.send = self._send_full[:words]
         self.recv = torch.empty(self.world * words, dtype=torch.int32, device=self.device)
@@ -102,7 +120,7 @@ class DrawListExchange:
         base = self._send_full.data_ptr()
         self.pipe.run_device(frame, model=model, visible_bitmap=visible_bitmap, world_aabb=world_aabb,
                              draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4,
-                             async_=True, **({"wire": True} if self.wire else {}))
+                             async_=True, **({"wire": self.form} if self.form else {}))
         if kernel_done is not None:
             kernel_done.record()
         self._gather_and_merge()
@@ -110,9 +128,12 @@ class DrawListExchange:
 
     def _gather_and_merge(self):
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        merge = self.pipe.merge_wire_lists if self.wire else self.pipe.merge_draw_lists
-        merge(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(), self.merged_count.data_ptr(), async_=True,
-              chunk_capacity=self.capacity)
+        if self.form:
+            self.pipe.merge_wire_lists(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(), self.merged_count.data_ptr(),
+                                       async_=True, chunk_capacity=self.capacity, **({"packed": True} if self.form == 2 else {}))
+        else:
+            self.pipe.merge_draw_lists(self.recv.data_ptr(), self.world, self.stride, self.merged.data_ptr(), self.merged_count.data_ptr(),
+                                       async_=True, chunk_capacity=self.capacity)
 
     def complete(self):
         """Block until the frames issued so far are done. If the LAST one overflowed its tightened chunk,
@@ -174,7 +195,7 @@ class PipelinedExchange:
     versa); a collective kernel beside a shard kernel is not that shape — its workgroups wait for peers, never
     for this GPU's shard kernel, so they always drain (tests/fake_ccl/spin_rccl.hip rehearses exactly this)."""
 
-    def __init__(self, make_pipe, n_local, world, rank, device, frames=2, dist=None, torch=None, group=None, wire=True):
+    def __init__(self, make_pipe, n_local, world, rank, device, frames=2, dist=None, torch=None, group=None, wire=True, n_meshes=None):
         if torch is None:
             import torch
         self.torch = torch
@@ -182,7 +203,7 @@ class PipelinedExchange:
         # on a GPU every frame slot has its own stream; the CPU tests (gloo) run the same rotation on the host
         self.streams = [torch.cuda.Stream(device=device) if self.on_gpu else None for _ in range(frames)]
         self.pipes = [make_pipe(st.cuda_stream if st is not None else 0) for st in self.streams]
-        self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group, wire=wire)
+        self.exchanges = [DrawListExchange(p, n_local, world, rank, device, dist=dist, torch=torch, group=group, wire=wire, n_meshes=n_meshes)
                           for p in self.pipes]
         self.kernel_done = [torch.cuda.Event() if self.on_gpu else None for _ in range(frames)]
         self.last = None  # slot whose shard kernel was issued last

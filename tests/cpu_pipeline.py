@@ -6,10 +6,11 @@ import ctypes as C
 import numpy as np
 
 import oracle
-from renderer_amd.pipeline import DRAW_CMD_DTYPE, SHARD_HEADER_BYTES, wire_body_bytes
+from renderer_amd.pipeline import DRAW_CMD_DTYPE, SHARD_HEADER_BYTES, wire_body_bytes, wire_form, wire_index_bits
 
 WIRE_BLOCK = 256            # MIP_WIRE_BLOCK_COMMANDS
 WIRE_BLOCK_WORDS = 4 + 2 * WIRE_BLOCK
+WIRE_PACKED_BLOCK_WORDS = 4 + WIRE_BLOCK   # MIP_OUT_WIRE_PACKED: one word per record
 
 
 def encode_wire(cmds, mesh_of_cmd, far_of_cmd):
@@ -27,6 +28,43 @@ def encode_wire(cmds, mesh_of_cmd, far_of_cmd):
         rec[:n, 1] = np.asarray(mesh_of_cmd, np.uint32) | (np.asarray(far_of_cmd, np.uint32) << np.uint32(31))
         v[:, 4:] = rec.reshape(blocks, 2 * WIRE_BLOCK)
     return body
+
+
+def encode_wire_packed(cmds, mesh_of_cmd, far_of_cmd, first_instance_base, n_meshes):
+    """The PACKED wire form (MIP_OUT_WIRE_PACKED), restated in numpy: one word per command, instance index in the frame
+    | mesh << index_bits | far << 31; block header {firstIndex of the block's first command, first_instance_base,
+    index_bits, 0}. Returns the body as uint32 words (whole blocks; unused slots zero)."""
+    n = len(cmds)
+    bits = wire_index_bits(n_meshes)
+    blocks = (n + WIRE_BLOCK - 1) // WIRE_BLOCK
+    body = np.zeros(blocks * WIRE_PACKED_BLOCK_WORDS, np.uint32)
+    v = body.reshape(blocks, WIRE_PACKED_BLOCK_WORDS)
+    if n:
+        v[:, 0] = cmds["firstIndex"][::WIRE_BLOCK]
+        v[:, 1] = np.uint32(first_instance_base)
+        v[:, 2] = bits
+        idx = (cmds["firstInstance"] - np.uint32(first_instance_base)).astype(np.uint32)
+        assert int(idx.max()) < (1 << bits), "the frame does not fit a packed record"
+        rec = np.zeros(blocks * WIRE_BLOCK, np.uint32)
+        rec[:n] = idx | (np.asarray(mesh_of_cmd, np.uint32) << np.uint32(bits)) | (np.asarray(far_of_cmd, np.uint32) << np.uint32(31))
+        v[:, 4:] = rec.reshape(blocks, WIRE_BLOCK)
+    return body
+
+
+def unpack_wire(body, count):
+    """The packed body of `count` records as the 8-byte form's body (same blocks, records {firstInstance, mesh | far << 31})."""
+    blocks = (count + WIRE_BLOCK - 1) // WIRE_BLOCK
+    v = np.asarray(body[: blocks * WIRE_PACKED_BLOCK_WORDS], np.uint32).reshape(blocks, WIRE_PACKED_BLOCK_WORDS)
+    out = np.zeros((blocks, WIRE_BLOCK_WORDS), np.uint32)
+    out[:, 0] = v[:, 0]
+    r = v[:, 4:]
+    bits = v[:, 2:3]
+    low = r & np.uint32(0x7FFFFFFF)
+    rec = np.zeros((blocks, WIRE_BLOCK, 2), np.uint32)
+    rec[:, :, 0] = v[:, 1:2] + (low & ((np.uint32(1) << bits) - np.uint32(1)))
+    rec[:, :, 1] = (low >> bits) | (r & np.uint32(0x80000000))
+    out[:, 4:] = rec.reshape(blocks, 2 * WIRE_BLOCK)
+    return out.reshape(-1)
 
 
 def decode_wire(body, count, meshes):
@@ -60,6 +98,7 @@ class OraclePipeline:
     def __init__(self, scene):
         self.s = scene
         self.n = scene["n"]
+        self.n_meshes = len(scene["meshes"])
 
     def run_device(self, frame, model=0, visible_bitmap=0, draw_cmds=0, draw_count=0, draw_index_total=0,
                    world_aabb=0, async_=False, wire=False):
@@ -77,7 +116,10 @@ class OraclePipeline:
             inst = (r["draw_cmds"]["firstInstance"] - np.uint32(frame.first_instance_base)).astype(np.int64)
             cam = np.array(frame.cam_pos[:], np.float32)
             far = np.array([oracle.pick_lod(2, cam, s["pos"][i]) for i in inst], np.uint32)
-            body = encode_wire(r["draw_cmds"], s["mesh_id"][inst], far)
+            if wire_form(wire) == 2:
+                body = encode_wire_packed(r["draw_cmds"], s["mesh_id"][inst], far, frame.first_instance_base, len(s["meshes"]))
+            else:
+                body = encode_wire(r["draw_cmds"], s["mesh_id"][inst], far)
             _view(draw_cmds, body.nbytes, np.uint32)[:] = body
             _view(draw_count, 4, np.uint32)[0] = c
             if draw_index_total:
@@ -115,9 +157,9 @@ class OraclePipeline:
         oc[0] = len(merged)
         oc[1] = index_total
 
-    def merge_wire_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0):
+    def merge_wire_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0, packed=False):
         lists, totals = [], []
-        fits = (stride - SHARD_HEADER_BYTES) // (WIRE_BLOCK_WORDS * 4) * WIRE_BLOCK
+        fits = (stride - SHARD_HEADER_BYTES) // ((WIRE_PACKED_BLOCK_WORDS if packed else WIRE_BLOCK_WORDS) * 4) * WIRE_BLOCK
         capacity = min(chunk_capacity, fits) if chunk_capacity else fits
         for k in range(n_chunks):
             h = _view(chunks_ptr + k * stride, 8, np.uint32)
@@ -125,8 +167,8 @@ class OraclePipeline:
             if count > capacity:
                 count = capacity
                 self._overflow = True
-            body = _view(chunks_ptr + k * stride + SHARD_HEADER_BYTES, wire_body_bytes(count), np.uint32)
-            lists.append(decode_wire(body, count, self.s["meshes"]))
+            body = _view(chunks_ptr + k * stride + SHARD_HEADER_BYTES, wire_body_bytes(count, packed=packed), np.uint32)
+            lists.append(decode_wire(unpack_wire(body, count) if packed else body, count, self.s["meshes"]))
             totals.append(int(h[1]))
         merged, index_total = oracle.merge_draw_lists(lists, totals)
         _view(out_cmds_ptr, len(merged) * 20, np.uint8)[:] = merged.view(np.uint8).reshape(-1)

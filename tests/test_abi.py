@@ -134,7 +134,7 @@ def test_rust_binding_sizes_and_symbols_follow_the_header():
     rust_fns = set(re.findall(r"pub fn (mip_[a-z_]+)\(", text))
     assert rust_fns <= set(_declared_functions())
     assert {"mip_create", "mip_run", "mip_run_many", "mip_set_geometry", "mip_merge_draw_lists",
-            "mip_import_external_fd", "mip_release_external", "mip_merge_wire_lists", "mip_import_external_semaphore_fd",
+            "mip_import_external_fd", "mip_release_external", "mip_merge_wire_lists", "mip_merge_wire_lists_packed", "mip_wire_index_bits", "mip_import_external_semaphore_fd",
             "mip_wait_external", "mip_signal_external", "mip_release_external_semaphore"} <= rust_fns
     # argument counts of the calls whose signature changed with ABI 2 (header vs Rust extern block)
     header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)

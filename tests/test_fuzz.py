@@ -27,26 +27,30 @@ def _check_wire_form(ra, p, s, want, what):
     bases and all — and the merge kernel itself must agree (one chunk)."""
     import torch
 
-    from cpu_pipeline import decode_wire
+    from cpu_pipeline import decode_wire, unpack_wire
     from renderer_amd.pipeline import SHARD_HEADER_BYTES, make_frame
     from renderer_amd.sharded import chunk_stride_bytes
 
     n = s["n"]
     dev = torch.device("cuda", 0)
-    stride = chunk_stride_bytes(max(n, 1), wire=True)
-    chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
-    merged = torch.full((max(n, 1), 5), -1, dtype=torch.int32, device=dev)
-    scal = torch.zeros(2, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
     frame = make_frame(s["planes"], s["cam_pos"], first_instance_base=s["first_instance_base"], first_index_base=s["first_index_base"])
-    base = chunk.data_ptr()
-    p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire=True)
-    host = chunk.cpu().numpy().view(np.uint32)
-    count = int(host[0])
-    assert count == want["draw_count"] and int(host[1]) == want["draw_index_total"], what
-    assert decode_wire(host[SHARD_HEADER_BYTES // 4:], count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), what
-    p.merge_wire_lists(base, 1, stride, merged.data_ptr(), scal.data_ptr(), chunk_capacity=max(n, 1))
-    assert int(scal[0].item()) == count and merged[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
+    for form in (True, "packed"):  # 8-byte records, packed 4-byte records
+        stride = chunk_stride_bytes(max(n, 1), wire=form)
+        chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
+        merged = torch.full((max(n, 1), 5), -1, dtype=torch.int32, device=dev)
+        scal = torch.zeros(2, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        base = chunk.data_ptr()
+        p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire=form)
+        host = chunk.cpu().numpy().view(np.uint32)
+        count = int(host[0])
+        assert count == want["draw_count"] and int(host[1]) == want["draw_index_total"], (what, form)
+        body = host[SHARD_HEADER_BYTES // 4:]
+        if form == "packed":
+            body = unpack_wire(body, count)
+        assert decode_wire(body, count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), (what, form)
+        p.merge_wire_lists(base, 1, stride, merged.data_ptr(), scal.data_ptr(), chunk_capacity=max(n, 1), packed=form == "packed")
+        assert int(scal[0].item()) == count and merged[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), (what, form)
 
 
 @pytest.mark.gpu

@@ -384,7 +384,7 @@ open(out_path, "w").write("ok")
 '''
 
 
-@pytest.mark.parametrize("world,wire", [(2, 1), (3, 1), (2, 0)])
+@pytest.mark.parametrize("world,wire", [(2, 2), (3, 2), (2, 1), (2, 0)])
 def test_native_sharded_frame_with_several_ranks_on_one_gpu(ra, tmp_path, world, wire):
     """mip_comm_init / mip_run_sharded with world size 2 and 3: one process per rank, all on this box's one GPU,
     the collective library replaced through the MIP_COMM_LIBRARY seam by tests/fake_ccl (a shared-memory double of
@@ -393,7 +393,8 @@ def test_native_sharded_frame_with_several_ranks_on_one_gpu(ra, tmp_path, world,
     fake = str(tmp_path / "libfake_rccl.so")
     subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            os.path.join(ROOT, "tests", "fake_ccl", "fake_rccl.cpp"), "-o", fake, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
-    # wire = 1 (default): the lists travel as 8-byte records and the merge expands them; 0: as 20-byte commands
+    # wire = 2 (default): the lists travel as packed 4-byte records (the shards fit), 1: as 8-byte records, and the merge expands
+    # them; 0: as 20-byte commands
     env = dict(os.environ, MIP_COMM_LIBRARY=fake, MIP_TUNE_SHARD_WIRE=str(wire))
     id_path = str(tmp_path / "uid")
     procs = [subprocess.Popen([sys.executable, "-c", _SHARDED_RANK, ROOT, str(r), str(world), "90001", id_path, str(tmp_path / f"ok{r}")],

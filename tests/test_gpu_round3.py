@@ -46,7 +46,7 @@ def test_wire_list_is_the_command_list(ra, oracle_mod, n):
     oracle's command list, and expanding them against the mesh table gives the oracle's 20-byte commands back."""
     import torch
 
-    from cpu_pipeline import decode_wire, encode_wire
+    from cpu_pipeline import decode_wire, encode_wire, encode_wire_packed, unpack_wire
     from renderer_amd.pipeline import make_frame, wire_body_bytes
 
     s = ra.scene.make_scene(3, n=n)
@@ -90,6 +90,27 @@ def test_wire_list_is_the_command_list(ra, oracle_mod, n):
             assert np.array_equal(g[:, 4:].reshape(blocks, 256, 2)[live], r[:, 4:].reshape(blocks, 256, 2)[live]), f"order {order}: records"
             assert np.all(got[blocks * 516:] == 0x5A5A5A5A), "nothing is written past the last block"
             assert decode_wire(got, count, s["meshes"]).tobytes() == cmds.tobytes()
+            # the packed form (MIP_OUT_WIRE_PACKED) of the same frame, same kernel order
+            if order:
+                os.environ["MIP_TUNE_ORDER"] = order
+            try:
+                with ra.InstancePipeline(max_instances=n, max_meshes=64) as q:
+                    q.set_mesh_table(s["meshes"])
+                    q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+                    body.fill_(0x5A5A5A5A)
+                    scal.zero_()
+                    torch.cuda.synchronize()
+                    q.run_device(frame, draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire="packed")
+            finally:
+                os.environ.pop("MIP_TUNE_ORDER", None)
+            assert [int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist()] == [count, total]
+            got = body.cpu().numpy().view(np.uint32)
+            refp = encode_wire_packed(cmds, s["mesh_id"][inst], far, base, len(s["meshes"])).reshape(blocks, 260)
+            gp = got[: blocks * 260].reshape(blocks, 260)
+            assert np.array_equal(gp[:, :4], refp[:, :4]), f"order {order}: packed block headers {{firstIndex, base, index bits, 0}}"
+            assert np.array_equal(gp[:, 4:][live], refp[:, 4:][live]), f"order {order}: packed records"
+            assert np.all(got[blocks * 260:] == 0x5A5A5A5A), "nothing is written past the last packed block"
+            assert decode_wire(unpack_wire(got, count), count, s["meshes"]).tobytes() == cmds.tobytes()
         with pytest.raises(ra.MipError):  # the wire form cannot carry the per-triangle stage's counts
             p.run_device(frame, model=body.data_ptr(), draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), wire=True,
                          culled_index_buffer=body.data_ptr(), culled_index_capacity=4)
@@ -100,7 +121,7 @@ def test_wire_form_in_ordered_tiles_mode_and_with_non_finite_instances(ra, oracl
     arithmetic) instantiations carry it too."""
     import torch
 
-    from cpu_pipeline import decode_wire
+    from cpu_pipeline import decode_wire, unpack_wire
     from renderer_amd.pipeline import make_frame, wire_body_bytes
 
     dev = torch.device("cuda", 0)
@@ -120,6 +141,11 @@ def test_wire_form_in_ordered_tiles_mode_and_with_non_finite_instances(ra, oracl
             count = int(scal[0].item())
             assert count == want["draw_count"] and p.timings()["general_launches"] == 2  # the NaN / inf instances select the literal tier
             assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), ordered
+            scal.zero_()
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"]), draw_cmds=body.data_ptr(), draw_count=scal.data_ptr(), wire="packed")
+            assert int(scal[0].item()) == count and p.timings()["general_launches"] == 3
+            assert decode_wire(unpack_wire(body.cpu().numpy().view(np.uint32), count), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), ordered
 
 
 @pytest.mark.parametrize("n_global,world", [(10, 3), (70_001, 3), (1_000_000, 8)])
@@ -135,8 +161,10 @@ def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
     full = ra.scene.make_scene(3, n=n_global)
     want = run_oracle(oracle_mod, full, threads=8, want=("draw_cmds",))
     per = (n_global + world - 1) // world
-    strides = {w: chunk_stride_bytes(per, wire=w) for w in (True, False)}
-    recv = {w: torch.zeros(world * strides[w] // 4, dtype=torch.int32, device=dev) for w in (True, False)}
+    forms = (True, "packed", False)
+    strides = {w: chunk_stride_bytes(per, wire=w) for w in forms}
+    assert strides["packed"] < 0.52 * strides[True] or per < 512
+    recv = {w: torch.zeros(world * strides[w] // 4, dtype=torch.int32, device=dev) for w in forms}
     counts = []
     for r in range(world):
         lo, hi = shard_range(n_global, world, r)
@@ -145,7 +173,7 @@ def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
             p.set_mesh_table(sh["meshes"])
             p.set_instances(sh["pos"], sh["rot"], sh["scale"], sh["mesh_id"])
             frame = make_frame(full["planes"], full["cam_pos"], first_instance_base=lo)
-            for w in (True, False):
+            for w in forms:
                 base = recv[w].data_ptr() + r * strides[w]
                 p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire=w)
             counts.append(int(recv[True][r * strides[True] // 4].item()))
@@ -155,11 +183,13 @@ def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
     torch.cuda.synchronize()
     with ra.InstancePipeline(max_instances=1, max_meshes=64) as p:
         p.set_mesh_table(full["meshes"])
-        for w in (True, False):
+        for w in forms:
             merged.fill_(-1)
             torch.cuda.synchronize()
-            merge = p.merge_wire_lists if w else p.merge_draw_lists
-            merge(recv[w].data_ptr(), world, strides[w], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
+            if w:
+                p.merge_wire_lists(recv[w].data_ptr(), world, strides[w], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per, packed=w == "packed")
+            else:
+                p.merge_draw_lists(recv[w].data_ptr(), world, strides[w], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
             count, index_total = (int(x) & 0xFFFFFFFF for x in scal.cpu().tolist())
             assert count == want["draw_count"] and index_total == want["draw_index_total"], (w, count)
             assert merged[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), f"wire={w}"
@@ -176,6 +206,15 @@ def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
                 p.merge_wire_lists(small.data_ptr(), world, tight, merged.data_ptr(), scal.data_ptr(), chunk_capacity=cap)
             assert e.value.code == -4
             assert int(scal[0].item()) == sum(min(c, cap) for c in counts)
+            tightp = chunk_stride_bytes(cap, wire="packed")
+            smallp = torch.zeros(world * tightp // 4, dtype=torch.int32, device=dev)
+            for r in range(world):
+                smallp[r * tightp // 4:(r + 1) * tightp // 4] = recv["packed"][r * strides["packed"] // 4: r * strides["packed"] // 4 + tightp // 4]
+            torch.cuda.synchronize()
+            with pytest.raises(ra.MipError) as e:
+                p.merge_wire_lists(smallp.data_ptr(), world, tightp, merged.data_ptr(), scal.data_ptr(), chunk_capacity=cap, packed=True)
+            assert e.value.code == -4
+            assert int(scal[0].item()) == sum(min(c, cap) for c in counts)
         # a record that names a mesh outside the table is never followed: reported, expanded as mesh 0
         if counts[0] > 0:
             bad = recv[True].clone()
@@ -184,6 +223,13 @@ def test_wire_merge_equals_the_command_merge(ra, oracle_mod, n_global, world):
             with pytest.raises(ra.MipError) as e:
                 p.merge_wire_lists(bad.data_ptr(), world, strides[True], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
             assert e.value.code == -5 and "mesh" in str(e.value)
+            # the packed form: an index-bit count that cannot be (block header word 2) is reported, never used as a shift
+            badp = recv["packed"].clone()
+            badp[SHARD_HEADER_BYTES // 4 + 2] = 40
+            torch.cuda.synchronize()
+            with pytest.raises(ra.MipError) as e:
+                p.merge_wire_lists(badp.data_ptr(), world, strides["packed"], merged.data_ptr(), scal.data_ptr(), chunk_capacity=per, packed=True)
+            assert e.value.code == -5
         with pytest.raises(ra.MipError):  # a stride that cannot hold the capacity
             p.merge_wire_lists(recv[True].data_ptr(), world, 256, merged.data_ptr(), scal.data_ptr(), chunk_capacity=per)
 
@@ -296,7 +342,8 @@ def test_sharded_frames_beside_a_collective_that_spin_waits_on_the_device(ra, tm
     # the chunk a rank sent is the wire form: 8.06 B per command (+ header), 40 % of the 20-byte form
     per = (n_global + world - 1) // world
     sent = int(notes[0].split("sent=")[1])
-    assert sent == (32 + (per + 255) // 256 * 2064 + 255) // 256 * 256 < 0.41 * (32 + per * 20)
+    # the default form: packed 4-byte records (these shards fit beside the 64 mesh ids) — a fifth of the 20-byte commands
+    assert sent == (32 + (per + 255) // 256 * 1040 + 255) // 256 * 256 < 0.21 * (32 + per * 20)
 
 
 def test_pipelined_exchange_repairs_an_overflow_under_its_own_stream(ra, oracle_mod):
@@ -326,8 +373,9 @@ def test_pipelined_exchange_repairs_an_overflow_under_its_own_stream(ra, oracle_
             q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
             return q
 
-        for wire in (True, False):
+        for wire in (True, 1, False):  # packed records (they fit), 8-byte records, 20-byte commands
             px = PipelinedExchange(make_pipe, s["n"], 1, 0, dev, frames=2, wire=wire)
+            assert px.exchanges[0].form == (2 if wire is True else int(bool(wire)))
             frame_a = make_shard_frame(s["planes"], s["cam_pos"], s["n"], 1, 0)
             frame_b = make_shard_frame(planes_b, cam_b, s["n"], 1, 0)
             torch.cuda.synchronize()
@@ -684,4 +732,17 @@ def test_kernel_wire_bytes_equal_the_committed_fixture(ra):
         live.reshape(-1)[:count] = True
         assert np.array_equal(got[:, 4:].reshape(-1, 256, 2)[live], want[:, 4:].reshape(-1, 256, 2)[live])
         p.merge_wire_lists(base, 1, stride, merged.data_ptr(), scal.data_ptr(), chunk_capacity=n)
+        assert merged[:count].cpu().numpy().tobytes() == g["draw_cmds"].tobytes()
+        # the packed form (MIP_OUT_WIRE_PACKED) against its committed bytes
+        stride_p = chunk_stride_bytes(n, wire="packed")
+        chunk.zero_()
+        merged.zero_()
+        torch.cuda.synchronize()
+        p.run_device(frame, draw_cmds=base + SHARD_HEADER_BYTES, draw_count=base, draw_index_total=base + 4, wire="packed")
+        host = chunk.cpu().numpy().view(np.uint32)
+        assert int(host[0]) == count
+        got = host[SHARD_HEADER_BYTES // 4: SHARD_HEADER_BYTES // 4 + w["body_packed"].size].reshape(-1, 260)
+        want = w["body_packed"].reshape(-1, 260)
+        assert np.array_equal(got[:, :4], want[:, :4]) and np.array_equal(got[:, 4:][live], want[:, 4:][live])
+        p.merge_wire_lists(base, 1, stride_p, merged.data_ptr(), scal.data_ptr(), chunk_capacity=n, packed=True)
         assert merged[:count].cpu().numpy().tobytes() == g["draw_cmds"].tobytes()

@@ -32,7 +32,9 @@ def _worker(rank, world, init_file, n_global, tighten, out_dir, wire=True):
         pipe = OraclePipeline(shard)
         n_local = hi - lo
         ex = DrawListExchange(pipe, n_local, world, rank, torch.device("cpu"), dist=dist, torch=torch, wire=wire)
-        assert ex.wire == wire
+        assert ex.wire == bool(wire)
+        # True: packed (these shards fit beside 64 mesh ids); the integer 1 asks for 8-byte records; False: 20-byte commands
+        assert ex.form == (2 if wire is True else (1 if wire else 0))
         frame = make_shard_frame(full["planes"], full["cam_pos"], n_global, world, rank)
         bitmap = torch.zeros((n_local + 31) // 32 + 1, dtype=torch.int32)
         model = torch.zeros((max(n_local, 1), 16), dtype=torch.float32)
@@ -58,10 +60,12 @@ def _worker(rank, world, init_file, n_global, tighten, out_dir, wire=True):
 
 
 @pytest.mark.parametrize("world,n_global,tighten,wire", [(2, 20_000, False, True), (2, 4_097, True, True), (3, 1_000, True, True),
-                                                         (2, 1, False, True), (2, 4_097, True, False), (3, 1_000, False, False)])
+                                                         (2, 1, False, True), (2, 4_097, True, 1), (3, 1_000, True, 1),
+                                                         (2, 4_097, True, False), (3, 1_000, False, False)])
 def test_sharded_exchange_matches_unsharded_oracle(world, n_global, tighten, wire):
-    """wire=True: the lists travel as 8-byte records (MIP_OUT_WIRE) and the merge expands them; wire=False: as
-    20-byte commands (round 2). The merged list is the unsharded oracle's either way."""
+    """wire=True: the lists travel as packed 4-byte records (MIP_OUT_WIRE_PACKED; the shards fit), wire=1: as 8-byte records
+    (MIP_OUT_WIRE), and the merge expands them; wire=False: as 20-byte commands (round 2). The merged list is the
+    unsharded oracle's every time."""
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "init")
         mp.spawn(_worker, args=(world, init_file, n_global, tighten, d, wire), nprocs=world, join=True)
@@ -83,6 +87,10 @@ def test_shard_ranges_cover_everything():
     assert chunk_stride_bytes(0, wire=True) == 256 and chunk_stride_bytes(1, wire=True) == 2304
     assert chunk_stride_bytes(256, wire=True) == 2304 and chunk_stride_bytes(257, wire=True) == 4352
     assert chunk_stride_bytes(336_000, wire=True) / chunk_stride_bytes(336_000) < 0.41
+    # the packed form: blocks of 1040 B; ~20 % of the 20-byte form
+    assert chunk_stride_bytes(0, wire="packed") == 256 and chunk_stride_bytes(1, wire="packed") == 1280
+    assert chunk_stride_bytes(257, wire=2) == 2304
+    assert chunk_stride_bytes(336_000, wire="packed") / chunk_stride_bytes(336_000) < 0.21
 
 
 def test_wire_form_round_trips_through_the_numpy_restatement():
@@ -90,8 +98,11 @@ def test_wire_form_round_trips_through_the_numpy_restatement():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import oracle
-    from cpu_pipeline import WIRE_BLOCK_WORDS, decode_wire, encode_wire
+    from cpu_pipeline import WIRE_BLOCK_WORDS, WIRE_PACKED_BLOCK_WORDS, decode_wire, encode_wire, encode_wire_packed, unpack_wire
     from renderer_amd import scene
+    from renderer_amd.pipeline import wire_index_bits
+
+    assert [wire_index_bits(m) for m in (0, 1, 2, 3, 64, 65, 1 << 20, (1 << 31) - 1)] == [31, 31, 30, 29, 25, 24, 11, 0]
 
     for n in (0, 1, 255, 256, 257, 3000):
         s = scene.make_scene(3, n=max(n, 1))
@@ -104,6 +115,15 @@ def test_wire_form_round_trips_through_the_numpy_restatement():
         assert body.size == (len(cmds) + 255) // 256 * WIRE_BLOCK_WORDS
         back = decode_wire(body, len(cmds), s["meshes"])
         assert back.tobytes() == cmds.tobytes(), n
+        packed = encode_wire_packed(cmds, s["mesh_id"][inst], far, 77, len(s["meshes"]))
+        assert packed.size == (len(cmds) + 255) // 256 * WIRE_PACKED_BLOCK_WORDS
+        live = np.zeros(body.size, bool)  # the unused slots of the last block are zero in one form, {base, 0} in the other
+        for b in range(body.size // WIRE_BLOCK_WORDS):
+            k = min(256, len(cmds) - 256 * b)
+            live[b * WIRE_BLOCK_WORDS: b * WIRE_BLOCK_WORDS + 1] = True
+            live[b * WIRE_BLOCK_WORDS + 4: b * WIRE_BLOCK_WORDS + 4 + 2 * k] = True
+        assert np.array_equal(unpack_wire(packed, len(cmds))[live], body[live]), n
+        assert decode_wire(unpack_wire(packed, len(cmds)), len(cmds), s["meshes"]).tobytes() == cmds.tobytes(), n
 
 
 def _camera_b():
@@ -192,7 +212,7 @@ def test_wire_fixture_pins_the_byte_layout():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import oracle
-    from cpu_pipeline import decode_wire, encode_wire
+    from cpu_pipeline import decode_wire, encode_wire, encode_wire_packed, unpack_wire
 
     w = np.load(os.path.join(HERE, "golden", "ext", "wire_4097_bases.npz"))
     g = np.load(os.path.join(HERE, "golden", str(w["source"]) + ".npz"))
@@ -205,3 +225,10 @@ def test_wire_fixture_pins_the_byte_layout():
     # the layout itself: block b starts at word 516 b; word 0 = firstIndex of its first command; records from word 4
     assert int(w["body"][0]) == int(cmds["firstIndex"][0]) and int(w["body"][516]) == int(cmds["firstIndex"][256])
     assert int(w["body"][4]) == int(cmds["firstInstance"][0]) and int(w["body"][516 + 4 + 2]) == int(cmds["firstInstance"][257])
+    # the packed form of the same list: blocks of 260 words, header {firstIndex, first_instance_base, index bits (64 meshes: 25), 0},
+    # one word per record: instance index | mesh << 25 | far << 31
+    pk = w["body_packed"]
+    assert pk.size == 5 * 260 and np.array_equal(encode_wire_packed(cmds, g["mesh_id"][inst], far, g["first_instance_base"], len(g["meshes"])), pk)
+    assert [int(x) for x in pk[260:264]] == [int(cmds["firstIndex"][256]), int(g["first_instance_base"]), 25, 0]
+    assert int(pk[260 + 4 + 1]) == int(inst[257]) | (int(g["mesh_id"][inst[257]]) << 25) | (int(far[257]) << 31)
+    assert decode_wire(unpack_wire(pk, len(cmds)), len(cmds), g["meshes"]).tobytes() == cmds.tobytes()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the shard merge for R chunks shaped like the 10 M / 8-rank exchange: mip_merge_wire_lists (default, the wire form
+"""Times the shard merge for R chunks shaped like the 10 M / 8-rank exchange: mip_merge_wire_lists_packed (`merge_bench.py R packed`,
+the form the ranks exchange when it fits), mip_merge_wire_lists (default, the 8-byte wire form
 the ranks exchange) or mip_merge_draw_lists (`merge_bench.py R cmds`, the 20-byte form of round 2)."""
 import os
 import sys
@@ -15,6 +16,8 @@ from renderer_amd.sharded import chunk_stride_bytes
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 WIRE = not (len(sys.argv) > 2 and sys.argv[2] == "cmds")
+if len(sys.argv) > 2 and sys.argv[2] == "packed":
+    WIRE = "packed"
 n = 1_250_000
 s = scene.make_scene(4, n=n)
 dev = torch.device("cuda", 0)
@@ -33,7 +36,11 @@ count = int(recv[0].item())
 merged = torch.zeros((R * cap, 5), dtype=torch.int32, device=dev)
 oc = torch.zeros(2, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
-merge = p.merge_wire_lists if WIRE else p.merge_draw_lists
+if WIRE == "packed":
+    def merge(*a, **kw):
+        p.merge_wire_lists(*a, packed=True, **kw)
+else:
+    merge = p.merge_wire_lists if WIRE else p.merge_draw_lists
 for _ in range(5):
     merge(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap)
 p.reset_timings()
@@ -41,6 +48,6 @@ for _ in range(20):
     merge(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap)
 t = p.timings()
 ms = t["total_merge_ms"] / t["merges"]
-per_cmd = (8.0625 + 20) if WIRE else 40
-print(f"{'wire' if WIRE else '20-byte'} form, {R} chunks x {count} cmds: merge {ms*1e3:.1f} us, {R*count*per_cmd/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
+per_cmd = (4.0625 + 20) if WIRE == "packed" else ((8.0625 + 20) if WIRE else 40)
+print(f"{'packed wire' if WIRE == 'packed' else ('wire' if WIRE else '20-byte')} form, {R} chunks x {count} cmds: merge {ms*1e3:.1f} us, {R*count*per_cmd/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
 p.close()
