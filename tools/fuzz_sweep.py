@@ -62,23 +62,27 @@ for seed in range(first, first + seeds):
         p.set_mesh_table(s["meshes"])
         p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
         got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb)
-        if n:  # the same frame in the wire form, expanded by the merge kernel (one chunk) and by the numpy statement
-            from cpu_pipeline import decode_wire
+        if n:  # the same frame in both wire forms, expanded by the merge kernel (one chunk) and by the numpy statement
+            from cpu_pipeline import decode_wire, unpack_wire
             from renderer_amd.pipeline import SHARD_HEADER_BYTES
             from renderer_amd.sharded import chunk_stride_bytes
-            stride = chunk_stride_bytes(n, wire=True)
-            chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
-            merged = torch.full((n, 5), -1, dtype=torch.int32, device=dev)
-            mc = torch.zeros(2, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize()
-            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb), draw_cmds=chunk.data_ptr() + SHARD_HEADER_BYTES,
-                         draw_count=chunk.data_ptr(), draw_index_total=chunk.data_ptr() + 4, wire=True)
-            host = chunk.cpu().numpy().view(np.uint32)
-            p.merge_wire_lists(chunk.data_ptr(), 1, stride, merged.data_ptr(), mc.data_ptr(), chunk_capacity=n)
-            if not (int(host[0]) == want["draw_count"] and int(host[1]) == want["draw_index_total"]
-                    and decode_wire(host[SHARD_HEADER_BYTES // 4:], int(host[0]), s["meshes"]).tobytes() == want["draw_cmds"].tobytes()
-                    and merged[: int(host[0])].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()):
-                fail(seed, f"wire form n={n} ordered={ordered}")
+            for form in (True, "packed"):
+                stride = chunk_stride_bytes(n, wire=form)
+                chunk = torch.zeros(stride // 4, dtype=torch.int32, device=dev)
+                merged = torch.full((n, 5), -1, dtype=torch.int32, device=dev)
+                mc = torch.zeros(2, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=fib, first_index_base=fxb), draw_cmds=chunk.data_ptr() + SHARD_HEADER_BYTES,
+                             draw_count=chunk.data_ptr(), draw_index_total=chunk.data_ptr() + 4, wire=form)
+                host = chunk.cpu().numpy().view(np.uint32)
+                p.merge_wire_lists(chunk.data_ptr(), 1, stride, merged.data_ptr(), mc.data_ptr(), chunk_capacity=n, packed=form == "packed")
+                body = host[SHARD_HEADER_BYTES // 4:]
+                if form == "packed":
+                    body = unpack_wire(body, int(host[0]))
+                if not (int(host[0]) == want["draw_count"] and int(host[1]) == want["draw_index_total"]
+                        and decode_wire(body, int(host[0]), s["meshes"]).tobytes() == want["draw_cmds"].tobytes()
+                        and merged[: int(host[0])].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()):
+                    fail(seed, f"wire form {form} n={n} ordered={ordered}")
         if not (np.array_equal(got["visible_bitmap"], want["visible_bitmap"]) and got["draw_count"] == want["draw_count"]
                 and got["draw_cmds"].tobytes() == want["draw_cmds"].tobytes() and got["draw_index_total"] == want["draw_index_total"]
                 and same(got["model"], want["model"]) and same(got["world_aabb"], want["world_aabb"])):
