@@ -43,7 +43,11 @@ extern "C" {
 #define MIP_ERR_CAPACITY (-4)         /* more instances / meshes than the context was created for */
 #define MIP_ERR_DEVICE (-5)           /* a HIP runtime call failed; see mip_last_error */
 #define MIP_ERR_NOT_READY (-6)        /* run before instances / mesh table were set */
-#define MIP_ERR_TIMEOUT (-7)          /* a bounded in-kernel wait expired; outputs are invalid */
+#define MIP_ERR_TIMEOUT (-7)          /* a bounded in-kernel wait expired; outputs are invalid. Reported only when the library could
+                                       * not issue the affected frames again itself: it does that (ordered tiles from then on,
+                                       * MipTimings.timeout_recoveries) whenever every frame slot carried at most one frame since
+                                       * the last mip_wait and nothing unrepeatable was in flight — a recorded mip_run_many
+                                       * round, a multi-view or sharded frame, an external-semaphore operation */
 
 /* ---- MipConfig.flags ---- */
 #define MIP_CFG_TIMING 0x1u /* bracket every kernel with hipEvents (mip_get_timings) */
@@ -195,6 +199,8 @@ typedef struct MipTimings {
   uint64_t three_pass_frames;  /* ordered-tiles frames that ran as three wait-free launches (large launches) instead of one ticketed one */
   uint64_t general_launches;  /* frames launched with the kernel that carries the literal path for non-finite
                                  inputs (some resident instance failed the upload-time finite test, or a skinned frame) */
+  uint64_t timeout_recoveries; /* times a bounded in-kernel wait expired and the library issued the affected frame(s) again itself
+                                 (see MIP_ERR_TIMEOUT): the caller saw MIP_OK and valid outputs */
 } MipTimings;
 
 /* Chunk header used by mip_merge_draw_lists: what each rank contributes to the

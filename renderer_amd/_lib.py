@@ -112,6 +112,7 @@ class MipTimings(C.Structure):
         ("sharded_bytes_sent", C.c_uint64),
         ("three_pass_frames", C.c_uint64),
         ("general_launches", C.c_uint64),
+        ("timeout_recoveries", C.c_uint64),
     ]
 
 

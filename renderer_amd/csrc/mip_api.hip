@@ -65,6 +65,15 @@ struct MipContext {
     uint32_t last_tag = 0;      // tag of the last launch (what the level-0 words hold now)
     uint32_t zero_buf = 2;      // which accumulator buffer is all-zero now: 0, 1, or 2 = both
     bool status_dirty = false;  // instance count changed: clear the prefix state before the next launch
+    // the frame issued last on this slot, kept so that a frame whose launch ran into MIP_ERR_TIMEOUT can be issued again
+    // in the mode the context has switched to (recover_from_timeout)
+    struct Replay {
+      uint32_t issued = 0;  // frames issued on this slot since the streams were last drained
+      MipFrame frame;
+      MipOutputs out;
+      bool skinned = false;
+      void* palette = nullptr;
+    } replay;
   };
   // mip_run_many replays: per slot one linear hipGraph of `frames` launches with baked tags
   // base_epoch+1 .. base_epoch+frames (see run_many_graphed).
@@ -149,6 +158,10 @@ struct MipContext {
   ncclComm_t comm = nullptr;
   uint32_t comm_rank = 0, comm_world = 0;
   uint32_t shard_cap_max = 0;  // largest max_instances over the ranks: what every rank sizes its chunks by
+  bool replay_blocked = false; // since the streams were last drained something was issued that cannot be issued again from a record:
+                               // a recorded round of mip_run_many, a multi-view or sharded frame, an external semaphore operation
+  bool recovering = false;
+  uint32_t last_error_bits = 0;
   int shard_wire = 2;          // what mip_run_sharded exchanges: 2 = the packed wire form whenever the largest shard fits it (else 1),
                                // 1 = 8-byte wire records, 0 = 20-byte commands (MIP_TUNE_SHARD_WIRE: A/B and tests)
   int sharded_form = 0;        // the form of the frame in flight (what the send buffer holds; repair_sharded_overflow re-sends it)
@@ -233,6 +246,7 @@ int32_t check_device_error(MipContext* ctx) {
     e |= ((volatile uint32_t*)ctx->h_error)[k];
     ((volatile uint32_t*)ctx->h_error)[k] = 0;
   }
+  ctx->last_error_bits = e;
   if (!e) return MIP_OK;
   int32_t repair_rc = MIP_OK;
   if (e & mip::kErrChunkOverflow) repair_rc = repair_sharded_overflow(ctx);
@@ -398,6 +412,13 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
 #ifdef MIP_DEBUG_STAMPS
   a.stamps = ctx->d_stamps;
   if (const char* env = std::getenv("MIP_DEBUG_SKIP_PUBLISH_TILE")) a.debug_skip_publish_tile = (uint32_t)std::atoi(env) + 1u;
+  if (const char* env = std::getenv("MIP_DEBUG_SKIP_PUBLISH_ONCE")) {  // fault injection for the transparent recovery: the first launches only
+    static int left = std::getenv("MIP_DEBUG_SKIP_PUBLISH_LAUNCHES") ? std::atoi(std::getenv("MIP_DEBUG_SKIP_PUBLISH_LAUNCHES")) : 1;
+    if (left > 0) {
+      --left;
+      a.debug_skip_publish_tile = (uint32_t)std::atoi(env) + 1u;
+    }
+  }
 #endif
 }
 
@@ -847,6 +868,8 @@ int32_t mip_set_instances_device(MipContext* ctx, const void* pos_xyz, const voi
   return set_instances_common(ctx, pos_xyz, rot_ijkw, scale, mesh_id, n, hipMemcpyDeviceToDevice);
 }
 
+static int32_t recover_from_timeout(MipContext* ctx, int32_t rc);
+
 static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, bool skinned, void* palette) {
   if (int32_t rc = validate_run(ctx, frame, out)) return rc;
   if (skinned && (out->flags & MIP_OUT_WIRE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE is not available for skinned frames");
@@ -861,6 +884,12 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
   ctx->last_slot = ctx->next_slot;
   ctx->next_slot = (ctx->next_slot + 1) % (uint32_t)ctx->slots.size();
   hipStream_t stream = sl.stream;
+  const bool alone = !ctx->pending_async;  // nothing else of this context is in flight: an error seen at the end of a synchronous frame is its own
+  sl.replay.issued += 1;
+  sl.replay.frame = *frame;
+  sl.replay.out = *out;
+  sl.replay.skinned = skinned;
+  sl.replay.palette = palette;
 
   const uint32_t n = ctx->n;
   const uint32_t words = (n + 31u) / 32u;
@@ -1069,7 +1098,48 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     ctx->timings.last_kernel_ms = ms;
     ctx->timings.total_kernel_ms += ms;
   }
-  return check_device_error(ctx);
+  int32_t rc = check_device_error(ctx);
+  if (alone) {
+    if (rc == MIP_ERR_TIMEOUT) rc = recover_from_timeout(ctx, rc);
+    if (!ctx->recovering) {
+      for (auto& s2 : ctx->slots) s2.replay.issued = 0;
+      ctx->replay_blocked = false;
+    }
+  }
+  return rc;
+}
+
+// A frame kernel's bounded wait has expired (kErrTimeout: the context has just switched itself to ordered tiles; kErrPartsTimeout: the
+// parts kernel of the per-triangle stage is off from now on). The frames that were in flight are on record, one per frame slot:
+// they are issued again — in the mode that cannot stall — and the caller gets their results instead of MIP_ERR_TIMEOUT (counted in
+// MipTimings.timeout_recoveries; the 0.5 s of the expired wait are the price). Not possible, and the error is reported as before,
+// when a slot carried more than one frame since the streams were last drained, or when something was in flight that is not on
+// record or has side effects elsewhere: a recorded round of mip_run_many, a multi-view or sharded frame (collective), an external
+// semaphore operation (its consumer may already have been released).
+static int32_t recover_from_timeout(MipContext* ctx, int32_t rc) {
+  constexpr uint32_t kRecoverable = mip::kErrTimeout | mip::kErrPartsTimeout;
+  const uint32_t bits = ctx->last_error_bits;
+  if (rc != MIP_ERR_TIMEOUT || ctx->recovering || ctx->replay_blocked || !(bits & kRecoverable) || (bits & ~kRecoverable)) return rc;
+  for (auto& sl : ctx->slots)
+    if (sl.replay.issued > 1) return rc;
+  ctx->recovering = true;
+  const uint32_t keep_next = ctx->next_slot, keep_last = ctx->last_slot;
+  int32_t again = MIP_OK;
+  for (size_t k = 0; k < ctx->slots.size() && again == MIP_OK; ++k) {
+    MipContext::FrameSlot::Replay r = ctx->slots[k].replay;  // a copy: run_frame overwrites the record
+    if (r.issued != 1) continue;
+    ctx->next_slot = (uint32_t)k;
+    if (r.out.flags & MIP_OUT_DEVICE) r.out.flags |= MIP_OUT_ASYNC;  // all slots first, one drain below (host outputs are synchronous by nature)
+    again = run_frame(ctx, &r.frame, &r.out, r.skinned, r.palette);
+  }
+  ctx->next_slot = keep_next;
+  ctx->last_slot = keep_last;
+  if (again == MIP_OK) again = sync_all(ctx);
+  if (again == MIP_OK) again = check_device_error(ctx);
+  ctx->pending_async = false;
+  ctx->recovering = false;
+  if (again == MIP_OK) ctx->timings.timeout_recoveries += 1;
+  return again;
 }
 
 // mip_run_many with the launches recorded once and replayed: per slot a linear hipGraph of
@@ -1213,6 +1283,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
       }
       MIP_HIP(ctx, hipMemcpyAsync(sl.d_frame_ring, stage, (size_t)G * mip::kFrameWords * 4, hipMemcpyHostToDevice, sl.stream));
       MIP_HIP(ctx, hipEventRecord(sl.stage_free[half], sl.stream));
+      ctx->replay_blocked = true;  // a recorded round is not on the per-slot record: no transparent recovery from a timeout
       MIP_HIP(ctx, hipGraphLaunch(fg.exec, sl.stream));
       sl.last_tag = fg.base_epoch + G;
       if (sl.epoch < sl.last_tag) sl.epoch = sl.last_tag;
@@ -1278,6 +1349,7 @@ static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const Mi
       return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "view %u: only visible_bitmap, draw_cmds, draw_count and draw_index_total are per view", v);
   }
   if (int32_t rc = bind_device(ctx)) return rc;
+  ctx->replay_blocked = true;  // a multi-view launch is not on the per-slot record
   const uint32_t n = ctx->n;
   hipStream_t stream = ctx->stream;
   if (n == 0) {
@@ -1508,8 +1580,11 @@ int32_t mip_wait(MipContext* ctx) {
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
   ctx->pending_async = false;
-  const int32_t rc = check_device_error(ctx);
+  int32_t rc = check_device_error(ctx);
   ctx->sharded_pending = 0;
+  if (rc == MIP_ERR_TIMEOUT) rc = recover_from_timeout(ctx, rc);
+  for (auto& sl : ctx->slots) sl.replay.issued = 0;
+  ctx->replay_blocked = false;
   return rc;
 }
 
@@ -1756,6 +1831,7 @@ int32_t mip_run_sharded(MipContext* ctx, const MipFrame* frame, const MipSharded
   if (!(out->flags & MIP_OUT_DEVICE)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "mip_run_sharded needs MIP_OUT_DEVICE");
   const uint32_t cap_max = ctx->shard_cap_max;
   const uint32_t cap = (out->chunk_capacity && out->chunk_capacity < cap_max) ? out->chunk_capacity : cap_max;
+  ctx->replay_blocked = true;  // a timed-out sharded frame is reported, never re-issued by one rank on its own (the exchange is collective)
   // 1. this rank's shard, written straight into its chunk (the send buffer always holds max_instances commands)
   MipOutputs local{};
   local.model = out->model;
@@ -1968,6 +2044,7 @@ int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint
   MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
+  ctx->replay_blocked = true;  // with a consumer ordered by semaphores a frame is never silently issued twice
   // the stream the NEXT frame will be enqueued on: that frame then starts only when the semaphore has been reached
   hipStream_t stream = ctx->slots[ctx->next_slot].stream;
   if (s->sem) {
@@ -1986,6 +2063,7 @@ int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, ui
   MipContext::ExternalSemaphore* s = find_semaphore(ctx, semaphore);
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
+  ctx->replay_blocked = true;
   // behind the frame that was issued last (its slot's stream)
   hipStream_t stream = ctx->slots[ctx->last_slot].stream;
   if (s->sem) {

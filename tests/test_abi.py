@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.MipConfig) == 32
     assert C.sizeof(_lib.MipFrame) == 24 * 4 + 3 * 4 + 8 + 64
     assert C.sizeof(_lib.MipOutputs) == 6 * 8 + 8 + 16 + 8
-    assert C.sizeof(_lib.MipTimings) == 96
+    assert C.sizeof(_lib.MipTimings) == 104
     assert MESH_DTYPE.itemsize == 80 and DRAW_CMD_DTYPE.itemsize == 20
     # compile the header as C and compare sizeof/offsetof with the Python mirrors
     src = r'''
@@ -59,7 +59,7 @@ def test_struct_layouts_match_header():
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [32, 80, 180, 80, 96, 20, 32, 76, 48]
+    assert sizes == [32, 80, 180, 80, 104, 20, 32, 76, 48]
     assert MESH_DTYPE.fields["vertex_offset"][1] == 76
 
 

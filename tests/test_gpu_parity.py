@@ -492,6 +492,70 @@ print("SAME", int(r["draw_cmds"].tobytes() == r2["draw_cmds"].tobytes() and (r["
     assert "SAME 1" in lines, out.stdout
 
 
+def test_a_timed_out_frame_is_issued_again_by_the_library():
+    """Fault injection (diagnostic build), one-shot: tile 5 of the FIRST launch(es) never publishes. The frame's bounded wait expires;
+    the library switches to ordered tiles and issues the frame(s) on record again itself: the caller sees MIP_OK and the right
+    outputs (MipTimings.timeout_recoveries counts it) — synchronously (host outputs), and at mip_wait for async frames on two frame
+    slots. With more than one frame per slot in flight the error is reported as before."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
+    code = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+mode = sys.argv[2]
+os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
+os.environ["MIP_DEBUG_SKIP_PUBLISH_ONCE"] = "5"
+os.environ["MIP_DEBUG_SKIP_PUBLISH_LAUNCHES"] = {"sync": "1", "async2": "2", "deep": "1"}[mode]
+import numpy as np, torch
+import renderer_amd
+from renderer_amd import scene
+from renderer_amd.pipeline import make_frame
+s = scene.make_scene(3, n=8192)
+q = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]), ordered_tiles=True)   # the reference result: never stalls
+q.set_mesh_table(s["meshes"]); q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+p = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]), frames_in_flight=1 if mode == "sync" else 2)
+p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+t0 = time.time()
+if mode == "sync":
+    r = p.run_host(s["planes"], s["cam_pos"])          # the stuck launch happens in here
+    want = q.run_host(s["planes"], s["cam_pos"])       # (the one-shot injection has been used up)
+    ok = r["draw_cmds"].tobytes() == want["draw_cmds"].tobytes() and (r["visible_bitmap"] == want["visible_bitmap"]).all() and r["draw_count"] > 0
+    print("SYNC", int(ok), p.timings()["timeout_recoveries"], "%.2f" % (time.time() - t0))
+else:
+    dev = torch.device("cuda", 0)
+    cams = [np.array(c, np.float32) for c in ((0, 1, 2), (5, 1, 2))]
+    bufs = [(torch.zeros((s["n"], 5), dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev)) for _ in cams]
+    torch.cuda.synchronize()
+    frames = 2 if mode == "async2" else 4
+    try:
+        for k in range(frames):
+            cmds, scal = bufs[k % 2]
+            p.run_device(make_frame(s["planes"], cams[k % 2]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, async_=True)
+        p.wait()
+        ok = True
+        for k in range(2):
+            want = q.run_host(s["planes"], cams[k])
+            c = int(bufs[k][1][0].item())
+            ok = ok and c == want["draw_count"] and bufs[k][0][:c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
+        print("ASYNC", int(ok), p.timings()["timeout_recoveries"])
+    except renderer_amd.MipError as e:
+        print("ERROR", e.code, p.timings()["timeout_recoveries"])
+'''
+    outs = {}
+    for mode in ("sync", "async2", "deep"):
+        out = subprocess.run([sys.executable, "-c", code, root, mode], capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stderr[-3000:]
+        outs[mode] = [l for l in out.stdout.split("\n") if l and l.split()[0] in ("SYNC", "ASYNC", "ERROR")]
+    assert outs["sync"] and outs["sync"][0].split()[:3] == ["SYNC", "1", "1"], outs           # right outputs, one recovery
+    assert 0.4 < float(outs["sync"][0].split()[3]) < 20.0, outs                                  # ... after the 0.5 s of the bounded wait
+    assert outs["async2"] == ["ASYNC 1 1"], outs                                                 # both slots' frames issued again at mip_wait
+    assert outs["deep"] == ["ERROR -7 0"], outs                                                  # two frames per slot: reported, not repeated
+
+
 def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):
     """Three frames in flight with different cameras and their own output buffers: all correct."""
     import torch
