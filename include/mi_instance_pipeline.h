@@ -47,7 +47,9 @@ extern "C" {
                                        * not issue the affected frames again itself: it does that (ordered tiles from then on,
                                        * MipTimings.timeout_recoveries) whenever every frame slot carried at most one frame since
                                        * the last mip_wait and nothing unrepeatable was in flight — a recorded mip_run_many
-                                       * round, a multi-view or sharded frame, an external-semaphore operation */
+                                       * round, a multi-view or sharded frame, a merge, an external-semaphore operation, an
+                                       * asynchronous frame on a caller-owned stream (MipConfig.stream: work the caller queued
+                                       * behind the frame has already consumed the invalid result) */
 
 /* ---- MipConfig.flags ---- */
 #define MIP_CFG_TIMING 0x1u /* bracket every kernel with hipEvents (mip_get_timings) */

@@ -1114,14 +1114,19 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
 // they are issued again — in the mode that cannot stall — and the caller gets their results instead of MIP_ERR_TIMEOUT (counted in
 // MipTimings.timeout_recoveries; the 0.5 s of the expired wait are the price). Not possible, and the error is reported as before,
 // when a slot carried more than one frame since the streams were last drained, or when something was in flight that is not on
-// record or has side effects elsewhere: a recorded round of mip_run_many, a multi-view or sharded frame (collective), an external
-// semaphore operation (its consumer may already have been released).
+// record or has side effects elsewhere: a recorded round of mip_run_many, a multi-view or sharded frame (collective), a merge (it
+// has consumed a frame's list), an external semaphore operation (its consumer may already have been released), an asynchronous
+// frame on a caller-owned stream (the caller may have queued consumers behind it).
 static int32_t recover_from_timeout(MipContext* ctx, int32_t rc) {
   constexpr uint32_t kRecoverable = mip::kErrTimeout | mip::kErrPartsTimeout;
   const uint32_t bits = ctx->last_error_bits;
   if (rc != MIP_ERR_TIMEOUT || ctx->recovering || ctx->replay_blocked || !(bits & kRecoverable) || (bits & ~kRecoverable)) return rc;
-  for (auto& sl : ctx->slots)
+  for (auto& sl : ctx->slots) {
     if (sl.replay.issued > 1) return rc;
+    // an asynchronous frame on a stream the CALLER owns (MipConfig.stream) may have consumers queued behind it that the library
+    // cannot see (renderer_amd/sharded.py: the all-gather of the frame's list): they have run on the invalid result
+    if (sl.replay.issued == 1 && (sl.replay.out.flags & MIP_OUT_ASYNC) && !sl.own_stream) return rc;
+  }
   ctx->recovering = true;
   const uint32_t keep_next = ctx->next_slot, keep_last = ctx->last_slot;
   int32_t again = MIP_OK;
@@ -1590,6 +1595,7 @@ int32_t mip_wait(MipContext* ctx) {
 
 static int32_t enqueue_merge(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
                              uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count) {
+  ctx->replay_blocked = true;  // a merge consumes frame outputs: a frame behind it is never silently issued again
   mip::MergeArgs a{};
   a.chunks = (const unsigned char*)chunks;
   a.stride = chunk_stride_bytes;
@@ -1652,6 +1658,7 @@ static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t 
   static_assert(MIP_WIRE_BLOCK_COMMANDS == mip::kWireBlockCmds && MIP_WIRE_BLOCK_BYTES == mip::kWireBlockWords * 4u &&
                 MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u && MIP_WIRE_PACKED_BLOCK_BYTES == mip::kWirePackedBlockWords * 4u,
                 "wire layout: header and kernels agree");
+  ctx->replay_blocked = true;  // (as enqueue_merge)
   mip::MergeWireArgs a{};
   a.chunks = (const unsigned char*)chunks;
   a.stride = chunk_stride_bytes;
