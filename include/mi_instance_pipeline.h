@@ -57,16 +57,16 @@ extern "C" {
                                      * The default relies on the hardware starting a launch's workgroups in index
                                      * order (true for a launch that has the chip to itself; NOT guaranteed by HIP,
                                      * and seen to fail when spin-waiting launches of several PROCESSES shared one
-                                     * GPU: such a frame ends with MIP_ERR_TIMEOUT after a bounded wait — 0.5 s and
-                                     * 2^18 polls — its outputs are invalid, and the context switches itself to this
-                                     * mode for every later frame). With this flag the cross-tile prefix cannot stall
+                                     * GPU: such a frame's bounded wait — 0.5 s and 2^18 polls — expires, the context
+                                     * switches itself to this mode for good and issues the frame again, or reports
+                                     * MIP_ERR_TIMEOUT when it cannot: see there). With this flag the cross-tile prefix cannot stall
                                      * whatever order workgroups start in, other tenants included. Small launches (up to
                                      * 512 tiles = 131 072 instances) take their tile numbers from a counter — one
                                      * returning atomic on ONE address per workgroup, ~11 ns each and serialised: 9.7
                                      * instead of 5.6 us at 100 k instances; larger ones run as THREE launches none of
-                                     * which waits for another workgroup (per-tile aggregates, their scan, the frame
-                                     * kernel reading its prefix: the instance data is read twice): 31.7 instead of
-                                     * 18.6 us at 1 M instances, 278 instead of 179 at 10 M (tickets: 56 / 463;
+                                     * which waits for another workgroup (the frame kernel without commands, a scan of its
+                                     * per-tile counts, the commands from the visibility bitmap): 25.8 instead of
+                                     * 18.6 us at 1 M instances, 214 instead of 180 at 10 M (tickets: 56 / 464;
                                      * DESIGN.md section 14.8). Set it when the GPU is shared with other compute that waits
                                      * on the device. mip_run_views runs one frame per view in this mode. */
 

@@ -46,6 +46,7 @@ namespace mip {
 constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
+constexpr uint32_t kTileGroup = 64;       // ordered tiles, large launches: tiles per group accumulator (see "the prefix without any wait")
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
@@ -83,9 +84,9 @@ struct KernelArgs {
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
   uint32_t* tile_ticket;        // ordered-tiles variant only: next tile number, 0 between launches
-  const uint2* tile_prefix;     // ordered-tiles variant only, large launches: the exclusive prefix {count, sum index_len} of every tile,
-                                // computed by two launches in front of this one (mip_tile_aggregate_kernel, mip_tile_scan_kernel): then
-                                // the tile number is blockIdx.x again and the kernel neither takes a ticket, nor publishes, nor waits
+  uint2* tile_agg_out;          // ordered-tiles variant only, large launches (launch 1 of 3, cmds == null): the tile's {count, sum index_len}
+                                // goes here; tile = blockIdx.x, nothing is published or waited for; mip_tile_scan_kernel and
+                                // mip_emit_commands_kernel (emit_kernel.hpp) turn the pairs and the visibility bitmap into the list
   const float* box_override;    // n*8 or null: per-instance mesh-space box {min xyz, -, max xyz, -} that replaces the mesh table's (skinned instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
@@ -688,10 +689,11 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   if constexpr (kTicketedTiles) {
     __shared__ uint32_t s_tile;
     if (tid == 0) {
-      s_tile = a.tile_prefix ? blockIdx.x : atomicAdd(a.tile_ticket, 1u);
+      const bool no_ticket = a.tile_agg_out != nullptr;
+      s_tile = no_ticket ? blockIdx.x : atomicAdd(a.tile_ticket, 1u);
       // the holder of the last ticket knows every other workgroup already has its own: it re-arms
       // the counter for the next launch on this frame slot
-      if (!a.tile_prefix && s_tile == a.n_tiles - 1u) __hip_atomic_store(a.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!no_ticket && s_tile == a.n_tiles - 1u) __hip_atomic_store(a.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_tile_agg = 0ull;
     }
     __syncthreads();
@@ -814,8 +816,16 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     // Published before any bulk store of this wave and without waiting for a barrier: the
     // successors' look-ups depend on it, nothing else does.
     bool publish = ((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish;
-    if constexpr (kTicketedTiles) publish = publish && a.tile_prefix == nullptr;  // three-pass mode: nobody looks
     if (publish) publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
+  }
+  if constexpr (kTicketedTiles) {
+    // launch 1 of a large ordered frame: no commands here, only the tile's aggregate — written by the last wave to get here
+    if (a.tile_agg_out && lane == 63u) {
+      const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | (uint32_t)__popcll(keep_mask);
+      const unsigned long long all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
+      // (adding the pair to a per-group accumulator here — 64 agent-scope atomic adds per address — cost this launch 10 us at 1 M)
+      if (((uint32_t)all >> kAggArrivalShift) == kWaves) a.tile_agg_out[tile] = make_uint2((uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
+    }
   }
 
   // ---- stage the matrix rows for the transposed store (three conflict-free ds_write_b128, 48-B pitch) ----
@@ -921,18 +931,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     MIP_STAMP(3);
     if (wave != 0) return;
     uint32_t base_count = 0, base_sum = 0;
-    bool given = false;
-    if constexpr (kTicketedTiles) given = a.tile_prefix != nullptr;
-    if (given) {  // three-pass mode: the scan launch in front of this one has left the tile's prefix (and the totals) in memory
-      const uint2 pre = a.tile_prefix[tile];
-      base_count = pre.x;
-      base_sum = pre.y;
-    } else {
-      if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
-      if (lane == 0 && tile == a.n_tiles - 1u) {
-        *a.draw_count = base_count + tile_count;
-        if (a.index_total) *a.index_total = base_sum + tile_sum;
-      }
+    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+    if (lane == 0 && tile == a.n_tiles - 1u) {
+      *a.draw_count = base_count + tile_count;
+      if (a.index_total) *a.index_total = base_sum + tile_sum;
     }
     MIP_STAMP(4);
     const uint32_t first_index_add = base_sum + first_index_base;
@@ -1007,16 +1009,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 
   // ---- exclusive prefix over the earlier tiles ----
   uint32_t base_count = 0, base_sum = 0;
-  bool given = false;
-  if constexpr (kTicketedTiles) given = a.tile_prefix != nullptr;
 #ifndef MIP_EXP_NO_HOP  // tuning builds only: what the kernel costs without the cross-tile look-up (results are wrong)
-  if (given) {  // three-pass mode (see order 1)
-    const uint2 pre = a.tile_prefix[tile];
-    base_count = pre.x;
-    base_sum = pre.y;
-  } else if (tile > 0) {
-    resolve_prefix(a, tile, lane, base_count, base_sum);
-  }
+  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
 #else
   base_count = tile * 64u;
 #ifdef MIP_EXP_FAKE_DELAY  // idle for the time a look-up takes, without its memory traffic
@@ -1026,7 +1020,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   }
 #endif
 #endif
-  if (!given && lane == 0 && tile == a.n_tiles - 1u) {
+  if (lane == 0 && tile == a.n_tiles - 1u) {
     *a.draw_count = base_count + tile_count;
     if (a.index_total) *a.index_total = base_sum + tile_sum;
   }
@@ -1058,99 +1052,60 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 // ---------------------------------------------------------------------------------------
 // ordered tiles, large launches: the prefix without any wait (three launches)
 // ---------------------------------------------------------------------------------------
-// MIP_CFG_ORDERED_TILES (or the fall-back after a MIP_ERR_TIMEOUT) must not depend on the order workgroups start in.
+// MIP_CFG_ORDERED_TILES (or a context that has had a stalled frame) must not depend on the order workgroups start in.
 // Tickets give that at ~11 ns per tile, serialised on one address: fine for small launches, 55 us at 1 M instances
 // against 18. From a few hundred thousand instances on the library instead runs THREE launches none of which ever
-// waits for another workgroup: (1) mip_tile_aggregate_kernel — the frame kernel's loads and arithmetic up to the keep
-// decision, nothing stored but one {count, sum index_len} pair per tile; (2) mip_tile_scan_kernel — one workgroup turns
-// the pairs into exclusive prefixes and writes the totals (draw_count, index total); (3) the frame kernel itself
-// (its ticketed instantiation with KernelArgs.tile_prefix set): tile = blockIdx.x, prefix read from memory, no ticket,
-// no publish, no look-up. The instance data is read twice and the keep decision computed twice — identical code
-// (keep_decision below is what the frame kernel evaluates), hence identical bits.
-struct TileAggregateArgs {
-  KernelArgs k;     // the frame's arguments (inputs, mesh table, frame, box override)
-  uint2* tile_agg;  // n_tiles pairs out
-};
-
-template <bool kBoxOverride, bool kGeneral>
-__global__ __launch_bounds__(kTile) void mip_tile_aggregate_kernel(const TileAggregateArgs ta) {
-  const KernelArgs& a = ta.k;
-  __shared__ uint32_t s_count[kWaves], s_sum[kWaves];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t tile = blockIdx.x;
-  const uint32_t i = tile * kTile + tid;
-  const bool active = i < a.n;
-  const uint32_t il = active ? i : a.n - 1u;
-  const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
-  const float4 q = a.rot[il];
-  const float sc = a.scale[il];
-  const uint32_t mesh = a.mesh_id[il];
-  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
-  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
-  MeshEntry mb;
-  mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
-  mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
-  float r[3][3];
-  quat_to_rotation(q.x, q.y, q.z, q.w, r);
-  Instance inst;
-  if constexpr (kGeneral) {  // the frame kernel's tier selection, verbatim
-    float mag = finite_magnitude(r, px, py, pz, sc);
-    if constexpr (kBoxOverride) {
-      const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;
-      const float4 lo = b4[0], hi = b4[1];
-      mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
-      mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
-    }
-    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
-    mag += box_abs;
-    const bool all_finite = mag < kFiniteLimit;
-    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
-    if (__builtin_expect(__any(!separable), 0)) {
-      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
-      else instance_fast(r, px, py, pz, sc, mb, inst);
-    } else {
-      instance_separable(r, px, py, pz, sc, mb, inst);
-    }
-  } else {
-    instance_separable(r, px, py, pz, sc, mb, inst);
-  }
-  const bool culled = coarse_culled(inst, a.planes);
-  const bool visible = active && !culled;
-  const float dx = a.cam[0] - px, dy = a.cam[1] - py, dz = a.cam[2] - pz;
-  const float dist_sq = dx * dx + dy * dy + dz * dz;
-  const uint32_t len = dist_sq > kLodDistSqThreshold ? mb.len1 : mb.len0;
-  const bool keep = visible && len > 0u;
-  const uint32_t count = (uint32_t)__popcll(__ballot(keep));
-  const uint32_t sum = wave_sum(visible ? len : 0u);
-  if (lane == 0u) { s_count[wave] = count; s_sum[wave] = sum; }
-  __syncthreads();
-  if (tid == 0u) {
-    uint32_t c = 0, s = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kWaves; ++w) { c += s_count[w]; s += s_sum[w]; }
-    ta.tile_agg[tile] = make_uint2(c, s);
-  }
-}
-
+// waits for another workgroup:
+//   1  the frame kernel without commands (its ticketed instantiation with KernelArgs.tile_agg_out set: tile = blockIdx.x, no
+//      ticket, no publish, no look-up): matrices, boxes, TLAS rows, the visibility bitmap; per tile the pair {emitted commands,
+//      sum of index_len};
+//   2  mip_tile_scan_kernel (below): one workgroup sums the pairs of every group of kTileGroup consecutive tiles (one coalesced
+//      load and a wave reduction per group), one scan across the workgroup gives the exclusive group prefixes and the totals
+//      (draw_count, index total) — 611 groups at 10 M instances;
+//   3  mip_emit_commands_kernel (emit_kernel.hpp): the commands, from the bitmap, the group prefix and the pairs of the earlier
+//      tiles of the own group.
+// (Round 3's first version ran an aggregate-only launch, a scan over all tiles and then the whole frame kernel with the prefix
+// given: 30.2 us at 1 M, 277 us at 10 M against this one's figures in profiles/r03_ordered_tiles_three_pass.txt.)
 struct TileScanArgs {
-  const uint2* tile_agg;
-  uint2* tile_prefix;
+  const uint2* tile_agg;   // n_tiles pairs {count, sum index_len} (launch 1)
+  uint2* group_prefix;     // exclusive prefix per group of kTileGroup tiles, out
   uint32_t n_tiles;
   uint32_t* draw_count;
   uint32_t* index_total;  // or null
 };
 
 // (static: this header is included by two translation units)
+// One workgroup of 16 waves. A group is kTileGroup = 64 consecutive tiles = what one wave loads in one coalesced instruction:
+// wave w takes groups w, w + 16, ... (independent loads, no barrier), reduces each across its lanes and leaves the sum in LDS;
+// after one barrier the up to 1 024 group sums are scanned across the workgroup. More than 65 536 tiles (16.7 M instances):
+// the outer loop runs again with the running totals.
 static __global__ __launch_bounds__(1024) __attribute__((unused)) void mip_tile_scan_kernel(const TileScanArgs a) {
+  __shared__ uint32_t s_gc[1024], s_gs[1024];
   __shared__ uint32_t s_c[16], s_s[16];
   __shared__ uint32_t s_run_c, s_run_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_groups = (a.n_tiles + kTileGroup - 1u) / kTileGroup;
   if (tid == 0u) { s_run_c = 0u; s_run_s = 0u; }
-  __syncthreads();
-  for (uint32_t base = 0; base < a.n_tiles; base += 1024u) {
-    const uint32_t t = base + tid;
-    const uint2 v = t < a.n_tiles ? a.tile_agg[t] : make_uint2(0u, 0u);
-    const uint32_t ic = wave_inclusive_scan(v.x), is = wave_inclusive_scan(v.y);
+  for (uint32_t base = 0; base < n_groups; base += 1024u) {
+    const uint32_t here = n_groups - base < 1024u ? n_groups - base : 1024u;
+    for (uint32_t g0 = wave; g0 < here; g0 += 64u) {  // four groups per step: their loads are in flight together
+      uint2 v[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = g0 + 16u * k;
+        const uint32_t t = (base + g) * kTileGroup + lane;
+        v[k] = (g < here && t < a.n_tiles) ? a.tile_agg[t] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t g = g0 + 16u * k;
+        const uint32_t c = wave_sum(v[k].x), s = wave_sum(v[k].y);
+        if (lane == 0u && g < here) { s_gc[g] = c; s_gs[g] = s; }
+      }
+    }
+    __syncthreads();
+    const uint32_t vc = tid < here ? s_gc[tid] : 0u, vs = tid < here ? s_gs[tid] : 0u;
+    const uint32_t ic = wave_inclusive_scan(vc), is = wave_inclusive_scan(vs);
     if (lane == 63u) { s_c[wave] = ic; s_s[wave] = is; }
     __syncthreads();
     uint32_t bc = s_run_c, bs = s_run_s, tc = 0, ts = 0;
@@ -1160,7 +1115,7 @@ static __global__ __launch_bounds__(1024) __attribute__((unused)) void mip_tile_
       tc += s_c[w];
       ts += s_s[w];
     }
-    if (t < a.n_tiles) a.tile_prefix[t] = make_uint2(bc + ic - v.x, bs + is - v.y);
+    if (tid < here) a.group_prefix[base + tid] = make_uint2(bc + ic - vc, bs + is - vs);
     __syncthreads();
     if (tid == 0u) { s_run_c += tc; s_run_s += ts; }
     __syncthreads();

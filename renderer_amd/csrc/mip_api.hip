@@ -53,8 +53,9 @@ struct MipContext {
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
     bool parts_dirty = false;                //                     a parts launch timed out: clear the granules before the next one
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
-    uint2* d_tile_agg = nullptr;             // ordered tiles, large launches (three-pass mode): per tile {count, sum}, then their exclusive prefixes
-    uint2* d_tile_prefix = nullptr;
+    uint2* d_tile_agg = nullptr;             // ordered tiles, large launches (three launches): per tile {count, sum};
+    uint2* d_group_prefix = nullptr;         //                                                   per group of 64 tiles the exclusive prefix;
+    uint32_t* d_vis_scratch = nullptr;       //                                                   the frame's visibility bitmap when the caller did not ask for it
     // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
     // refreshed before every replay from one of two pinned staging halves
     uint32_t* d_frame_ring = nullptr;
@@ -552,7 +553,8 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_part_status);
     (void)hipFree(sl.d_skin_box);
     (void)hipFree(sl.d_tile_agg);
-    (void)hipFree(sl.d_tile_prefix);
+    (void)hipFree(sl.d_group_prefix);
+    (void)hipFree(sl.d_vis_scratch);
     (void)hipFree(sl.d_frame_ring);
     if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
     for (auto& e : sl.stage_free)
@@ -951,29 +953,55 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       mip::launch_skinned_bounds((n + per_block - 1) / per_block, stream, k);
       MIP_HIP(ctx, hipGetLastError());
     }
+    bool frame_launched = false;
     if (a.cmds && ctx->ordered_tiles && a.n_tiles > ctx->ordered_three_pass_min_tiles) {
-      // ordered tiles, large launch: two wait-free launches produce every tile's prefix, the frame kernel then reads it
-      // (instance_kernel.hpp, "the prefix without any wait")
+      // ordered tiles, large launch: three launches none of which waits for another workgroup
+      // (instance_kernel.hpp, "the prefix without any wait"; emit_kernel.hpp)
       const size_t tiles_cap = tiles_for(ctx->max_instances ? ctx->max_instances : 1);
+      const size_t groups_cap = (tiles_cap + mip::kTileGroup - 1) / mip::kTileGroup;
       if (!sl.d_tile_agg) MIP_HIP(ctx, hipMalloc(&sl.d_tile_agg, tiles_cap * sizeof(uint2)));
-      if (!sl.d_tile_prefix) MIP_HIP(ctx, hipMalloc(&sl.d_tile_prefix, tiles_cap * sizeof(uint2)));
-      mip::TileAggregateArgs ta{};
-      ta.k = a;
-      ta.tile_agg = sl.d_tile_agg;
-      const bool general = skinned || ctx->nonfinite_instances != 0 || ctx->force_general;
-      mip::launch_tile_aggregate(skinned, general, a.n_tiles, stream, ta);
+      if (!sl.d_group_prefix) MIP_HIP(ctx, hipMalloc(&sl.d_group_prefix, groups_cap * sizeof(uint2)));
+      // 1: the frame kernel without commands — matrices, boxes, TLAS rows, the visibility bitmap — leaves one pair per tile
+      if (!a.bitmap) {  // the caller did not ask for the bitmap: launch 3 still needs it
+        if (!sl.d_vis_scratch) MIP_HIP(ctx, hipMalloc(&sl.d_vis_scratch, ((size_t)(ctx->max_instances ? ctx->max_instances : 1) + 31) / 32 * 4));
+        a.bitmap = sl.d_vis_scratch;
+      }
+      mip::KernelArgs a1 = a;
+      a1.cmds = nullptr; a1.draw_count = nullptr; a1.index_total = nullptr; a1.src_index_offset = nullptr;
+      a1.tile_agg_out = sl.d_tile_agg;
+      void* params[1] = {&a1};
+      if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
+      uint32_t grid = 0;
+      const FrameKernel kernel = select_frame_kernel(ctx, skinned, 0, &grid);  // ordered tiles: the ticketed instantiation
+      MIP_HIP(ctx, hipLaunchKernel((const void*)kernel, dim3(grid), dim3(mip::kTile), params, ctx->lds_pad, stream));
+      frame_launched = true;
+      // 2: exclusive prefixes of the group sums + the totals
       mip::TileScanArgs ts{};
       ts.tile_agg = sl.d_tile_agg;
-      ts.tile_prefix = sl.d_tile_prefix;
+      ts.group_prefix = sl.d_group_prefix;
       ts.n_tiles = a.n_tiles;
       ts.draw_count = a.draw_count;
       ts.index_total = a.index_total;
       hipLaunchKernelGGL(mip::mip_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
       MIP_HIP(ctx, hipGetLastError());
-      a.tile_prefix = sl.d_tile_prefix;
+      // 3: the commands, from the bitmap and the prefixes
+      mip::EmitArgs e{};
+      e.pos = a.pos; e.mesh_id = a.mesh_id; e.meshes = a.meshes; e.mesh_draw = a.mesh_draw;
+      e.bitmap = a.bitmap;
+      e.tile_agg = sl.d_tile_agg;
+      e.group_prefix = sl.d_group_prefix;
+      e.cmds = a.cmds;
+      e.src_index_offset = a.src_index_offset;
+      e.n = n;
+      e.first_instance_base = a.first_instance_base;
+      e.first_index_base = a.first_index_base;
+      e.wire_index_bits = a.wire_index_bits;
+      std::memcpy(e.cam, a.cam, sizeof e.cam);
+      mip::launch_emit_commands(device_out ? wire_form(out->flags) : 0, a.n_tiles, stream, e);
+      MIP_HIP(ctx, hipGetLastError());
       ctx->timings.three_pass_frames += 1;
     }
-    {
+    if (!frame_launched) {
       void* params[1] = {&a};
       if (skinned || ctx->nonfinite_instances != 0 || ctx->force_general) ctx->timings.general_launches += 1;
       uint32_t grid = 0;

@@ -20,7 +20,6 @@ namespace mip {
 struct MeshEntry;   // instance_kernel.hpp
 struct MeshDraw;
 struct KernelArgs;
-struct TileAggregateArgs;
 
 // ---- row f-1: per-triangle stage (triangle_kernels.hpp) ----
 struct TriangleArgs {
@@ -163,7 +162,23 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in mip_api.hip.
 using FrameKernelFn = void (*)(const KernelArgs);
 FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */);
-// first of the three wait-free launches of a large ordered-tiles frame (mip_tile_aggregate_kernel, instance_kernel.hpp)
-void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a);
+// last of the three wait-free launches of a large ordered-tiles frame (emit_kernel.hpp): the command list from the bitmap
+struct EmitArgs {
+  const float* pos;
+  const uint32_t* mesh_id;
+  const MeshEntry* meshes;
+  const MeshDraw* mesh_draw;
+  const uint32_t* bitmap;          // visibility of the frame, written by launch 1
+  const uint2* tile_agg;           // {count, sum index_len} per tile, written by launch 1
+  const uint2* group_prefix;       // exclusive {count, sum index_len} per group of kTileGroup tiles, written by launch 2
+  uint32_t* cmds;                  // n*5 words, or a wire body
+  uint32_t* src_index_offset;      // or null (per-triangle stage)
+  uint32_t n;
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  uint32_t wire_index_bits;
+  float cam[3];
+};
+void launch_emit_commands(int wire /* 0 | 1 | 2 */, uint32_t tiles, hipStream_t stream, const EmitArgs& a);
 
 }  // namespace mip

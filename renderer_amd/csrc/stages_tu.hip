@@ -5,6 +5,7 @@
 #include "light_lists_kernel.hpp"
 #include "skinning_kernel.hpp"
 #include "views_kernel.hpp"
+#include "emit_kernel.hpp"
 
 namespace mip {
 
@@ -63,10 +64,10 @@ FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool
   return general ? commands_first<false, true, 0>(ticketed) : commands_first<false, false, 0>(ticketed);
 }
 
-void launch_tile_aggregate(bool box_override, bool general, uint32_t tiles, hipStream_t stream, const TileAggregateArgs& a) {
-  if (box_override) hipLaunchKernelGGL((mip_tile_aggregate_kernel<true, true>), dim3(tiles), dim3(kTile), 0, stream, a);
-  else if (general) hipLaunchKernelGGL((mip_tile_aggregate_kernel<false, true>), dim3(tiles), dim3(kTile), 0, stream, a);
-  else hipLaunchKernelGGL((mip_tile_aggregate_kernel<false, false>), dim3(tiles), dim3(kTile), 0, stream, a);
+void launch_emit_commands(int wire, uint32_t tiles, hipStream_t stream, const EmitArgs& a) {
+  if (wire == 2) hipLaunchKernelGGL(mip_emit_commands_kernel<2>, dim3(tiles), dim3(kTile), 0, stream, a);
+  else if (wire == 1) hipLaunchKernelGGL(mip_emit_commands_kernel<1>, dim3(tiles), dim3(kTile), 0, stream, a);
+  else hipLaunchKernelGGL(mip_emit_commands_kernel<0>, dim3(tiles), dim3(kTile), 0, stream, a);
 }
 
 }  // namespace mip

@@ -611,14 +611,15 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
 
 @pytest.mark.parametrize("min_tiles", ["0", "default"])
 def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
-    """MIP_CFG_ORDERED_TILES on large launches: three launches none of which waits for another workgroup (per-tile
-    aggregates, their scan, the frame kernel reading its prefix) instead of one ticket per tile. Same bytes as the default
-    kernel: plain frames at sizes either side of the switch, non-finite instances (literal tier in BOTH the aggregate pass
-    and the frame kernel), the wire form, bases, host outputs, the per-triangle stage (its scratch list and count), a
-    skinned frame (box override) and culled views. min_tiles=0 forces the mode onto every launch."""
+    """MIP_CFG_ORDERED_TILES on large launches: three launches none of which waits for another workgroup (the frame kernel
+    without commands leaving one pair per tile, the scan of the pairs by groups of 64 tiles, the commands from the visibility
+    bitmap: emit_kernel.hpp) instead of one ticket per tile. Same bytes as the default kernel: plain frames at sizes either
+    side of the switch, non-finite instances (literal tier), both wire forms, bases, host outputs (with and without a bitmap
+    of the caller's), the per-triangle stage (its scratch list, count and source offsets), a skinned frame (box override) and
+    culled views. min_tiles=0 forces the mode onto every launch."""
     import torch
 
-    from cpu_pipeline import decode_wire
+    from cpu_pipeline import decode_wire, unpack_wire
     from renderer_amd.pipeline import make_frame, wire_body_bytes
 
     if min_tiles != "default":
@@ -648,6 +649,21 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
             count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
             assert count == want["draw_count"] and total == want["draw_index_total"]
             assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), n
+            # the packed wire form, and device outputs WITHOUT a bitmap (the library's scratch bitmap feeds the last launch)
+            body.zero_()
+            scal.zero_()
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5), draw_cmds=body.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire="packed")
+            assert [int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist()] == [count, total]
+            assert decode_wire(unpack_wire(body.cpu().numpy().view(np.uint32), count), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), n
+            cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            scal.zero_()
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5), draw_cmds=cmds.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
+            assert [int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist()] == [count, total]
+            assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), n
     if min_tiles != "0":
         # frames issued from compiled code (mip_run_many) take the same path: large ordered launches are not recorded as graphs
         s = ra.scene.make_scene(3, n=300_000)
