@@ -676,6 +676,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
 void mip_destroy(MipContext* ctx) { free_all(ctx); }
 
 int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!meshes && m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "meshes is NULL");
   if (m > ctx->max_meshes) return fail(ctx, MIP_ERR_CAPACITY, "%u meshes > max_meshes %u", m, ctx->max_meshes);
@@ -747,6 +748,7 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
 }
 
 int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint32_t m) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!addresses && m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "addresses is NULL");
   if (!ctx->have_meshes || m != ctx->m) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u addresses for %u meshes", m, ctx->m);
@@ -763,6 +765,7 @@ int32_t mip_set_blas_addresses(MipContext* ctx, const uint64_t* addresses, uint3
 
 int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_vertices, const uint32_t* indices,
                          uint32_t n_indices) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if ((n_vertices && !vertex_xyz) || (n_indices && !indices)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL geometry");
   if (int32_t rc = bind_device(ctx)) return rc;
@@ -790,6 +793,7 @@ int32_t mip_set_geometry(MipContext* ctx, const float* vertex_xyz, uint32_t n_ve
 
 static int32_t set_instances_common(MipContext* ctx, const void* pos, const void* rot, const void* scale,
                                     const void* mesh_id, uint32_t n, hipMemcpyKind kind) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (n > ctx->max_instances)
     return fail(ctx, MIP_ERR_CAPACITY, "%u instances > max_instances %u", n, ctx->max_instances);
   if (n && (!pos || !rot || !scale || !mesh_id)) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL instance column");
@@ -838,6 +842,7 @@ int32_t mip_set_instances(MipContext* ctx, const float* pos_xyz, const float* ro
 
 int32_t mip_update_instances(MipContext* ctx, uint32_t first, uint32_t count, const float* pos_xyz, const float* rot_ijkw,
                              const float* scale, const uint32_t* mesh_id) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!ctx->have_instances) return fail(ctx, MIP_ERR_NOT_READY, "no resident instances to update");
   if ((uint64_t)first + count > ctx->n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "range [%u, %u) exceeds %u instances", first, first + count, ctx->n);
@@ -1485,6 +1490,7 @@ int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs*
 
 int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* inverse_bind, const float* joint_box,
                          uint32_t n_joints) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!parent || !inverse_bind || !joint_box) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "NULL skeleton array");
   static_assert(MIP_MAX_JOINTS == mip::kMaxJoints && MIP_POSE_FLOATS == mip::kPoseWords, "skinning limits");
@@ -1542,6 +1548,7 @@ int32_t mip_set_skeleton(MipContext* ctx, const int32_t* parent, const float* in
 }
 
 int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_t device) {
+  if (ctx && ctx->pending_async) ctx->replay_blocked = true;  // resident state changes: a frame in flight is never re-issued against the new state
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (!ctx->n_joints) return fail(ctx, MIP_ERR_NOT_READY, "set the skeleton before the poses");
   if (!ctx->have_instances || n != ctx->n) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "%u poses for %u instances", n, ctx->n);
