@@ -65,7 +65,7 @@ extern "C" {
                                      * returning atomic on ONE address per workgroup, ~11 ns each and serialised: 9.7
                                      * instead of 5.6 us at 100 k instances; larger ones run as THREE launches none of
                                      * which waits for another workgroup (the frame kernel without commands, a scan of its
-                                     * per-tile counts, the commands from the visibility bitmap): 25.8 instead of
+                                     * per-tile counts, the commands from the visibility bitmap): 26.0 instead of
                                      * 18.6 us at 1 M instances, 214 instead of 180 at 10 M (tickets: 56 / 464;
                                      * DESIGN.md section 14.8). Set it when the GPU is shared with other compute that waits
                                      * on the device. mip_run_views runs one frame per view in this mode. */

@@ -46,7 +46,8 @@ namespace mip {
 constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
-constexpr uint32_t kTileGroup = 64;       // ordered tiles, large launches: tiles per group accumulator (see "the prefix without any wait")
+constexpr uint32_t kTileGroup = 64;       // ordered tiles, large launches: tiles per group of the scan launch (see "the prefix without any wait")
+constexpr uint32_t kEmitSelfPrefixTiles = 4096;  // ... launches of at most this many tiles (1 M instances) have no scan launch: emit_kernel.hpp
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.

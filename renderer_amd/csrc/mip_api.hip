@@ -132,6 +132,7 @@ struct MipContext {
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t ordered_three_pass_min_tiles = 512;   // ordered tiles: launches of more tiles than this take three wait-free launches
+  uint32_t emit_self_prefix_tiles = mip::kEmitSelfPrefixTiles;  //   ... two, up to this many tiles (MIP_TUNE_EMIT_SELF_PREFIX_TILES; 0: always the scan launch)
                                                   // instead of one ticket per tile (MIP_TUNE_THREE_PASS_MIN_TILES; measured crossover
                                                   // in profiles/r03_ordered_tiles_three_pass.txt)
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
@@ -651,6 +652,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDERED_TILES")) ctx->ordered_tiles = std::atoi(env) != 0;
     if (const char* env = std::getenv("MIP_TUNE_THREE_PASS_MIN_TILES")) ctx->ordered_three_pass_min_tiles = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_EMIT_SELF_PREFIX_TILES")) ctx->emit_self_prefix_tiles = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_ORDER")) {
       const int v = std::atoi(env);
       if (v == 1 || v == 3) ctx->force_order = v;
@@ -980,21 +982,27 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
       const FrameKernel kernel = select_frame_kernel(ctx, skinned, 0, &grid);  // ordered tiles: the ticketed instantiation
       MIP_HIP(ctx, hipLaunchKernel((const void*)kernel, dim3(grid), dim3(mip::kTile), params, ctx->lds_pad, stream));
       frame_launched = true;
-      // 2: exclusive prefixes of the group sums + the totals
-      mip::TileScanArgs ts{};
-      ts.tile_agg = sl.d_tile_agg;
-      ts.group_prefix = sl.d_group_prefix;
-      ts.n_tiles = a.n_tiles;
-      ts.draw_count = a.draw_count;
-      ts.index_total = a.index_total;
-      hipLaunchKernelGGL(mip::mip_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
-      MIP_HIP(ctx, hipGetLastError());
+      // 2: exclusive prefixes of the group sums + the totals — only for launches too large for launch 3 to sum the pairs itself
+      const bool scan_launch = a.n_tiles > ctx->emit_self_prefix_tiles;
+      if (scan_launch) {
+        mip::TileScanArgs ts{};
+        ts.tile_agg = sl.d_tile_agg;
+        ts.group_prefix = sl.d_group_prefix;
+        ts.n_tiles = a.n_tiles;
+        ts.draw_count = a.draw_count;
+        ts.index_total = a.index_total;
+        hipLaunchKernelGGL(mip::mip_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, ts);
+        MIP_HIP(ctx, hipGetLastError());
+      }
       // 3: the commands, from the bitmap and the prefixes
       mip::EmitArgs e{};
       e.pos = a.pos; e.mesh_id = a.mesh_id; e.meshes = a.meshes; e.mesh_draw = a.mesh_draw;
       e.bitmap = a.bitmap;
       e.tile_agg = sl.d_tile_agg;
-      e.group_prefix = sl.d_group_prefix;
+      e.group_prefix = scan_launch ? sl.d_group_prefix : nullptr;
+      e.draw_count = a.draw_count;
+      e.index_total = a.index_total;
+      e.n_tiles = a.n_tiles;
       e.cmds = a.cmds;
       e.src_index_offset = a.src_index_offset;
       e.n = n;

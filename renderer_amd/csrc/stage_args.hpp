@@ -170,7 +170,11 @@ struct EmitArgs {
   const MeshDraw* mesh_draw;
   const uint32_t* bitmap;          // visibility of the frame, written by launch 1
   const uint2* tile_agg;           // {count, sum index_len} per tile, written by launch 1
-  const uint2* group_prefix;       // exclusive {count, sum index_len} per group of kTileGroup tiles, written by launch 2
+  const uint2* group_prefix;       // exclusive {count, sum index_len} per group of kTileGroup tiles, written by launch 2; null: there
+                                   // was no launch 2 (small launches), the kernel sums the earlier tiles' pairs itself and writes
+  uint32_t* draw_count;            // ... the totals (last tile); unused otherwise
+  uint32_t* index_total;           // or null
+  uint32_t n_tiles;
   uint32_t* cmds;                  // n*5 words, or a wire body
   uint32_t* src_index_offset;      // or null (per-triangle stage)
   uint32_t n;

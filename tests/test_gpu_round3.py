@@ -625,7 +625,12 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
     if min_tiles != "default":
         monkeypatch.setenv("MIP_TUNE_THREE_PASS_MIN_TILES", min_tiles)
     dev = torch.device("cuda", 0)
-    for n in ((1, 255, 4_097, 70_001) if min_tiles == "0" else (131_072, 131_073, 1_200_003)):
+    # launches of up to 4 096 tiles have no scan launch (the last launch sums the earlier tiles' pairs itself): 1 200 003 instances
+    # take the scan, and so does 70 001 with the switch forced (a partial last group of 64 tiles)
+    for n in ((1, 255, 4_097, 70_001, -70_001) if min_tiles == "0" else (131_072, 131_073, 1_200_003)):
+        if n < 0:
+            n = -n
+            monkeypatch.setenv("MIP_TUNE_EMIT_SELF_PREFIX_TILES", "0")
         s = ra.scene.make_scene(3, n=n)
         if n > 300:
             s["pos"][17] = np.nan
