@@ -131,10 +131,10 @@ struct MipContext {
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;     // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
-  uint32_t ordered_three_pass_min_tiles = 512;   // ordered tiles: launches of more tiles than this take three wait-free launches
-  uint32_t emit_self_prefix_tiles = mip::kEmitSelfPrefixTiles;  //   ... two, up to this many tiles (MIP_TUNE_EMIT_SELF_PREFIX_TILES; 0: always the scan launch)
+  uint32_t ordered_three_pass_min_tiles = 160;   // ordered tiles: launches of more tiles than this (40 960 instances) take wait-free launches
                                                   // instead of one ticket per tile (MIP_TUNE_THREE_PASS_MIN_TILES; measured crossover
-                                                  // in profiles/r03_ordered_tiles_three_pass.txt)
+                                                  // in profiles/r03_ordered_tiles_three_pass.txt: 32 k instances 6.3 against 6.5 us, 65 k 7.7 against 6.9)
+  uint32_t emit_self_prefix_tiles = mip::kEmitSelfPrefixTiles;  //   ... two launches up to this many tiles, three above (MIP_TUNE_EMIT_SELF_PREFIX_TILES; 0: always three)
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
                                    // measured (DamagedHelmet entry, frame time parts / workgroup-per-command): 30 instances 14 / 24 us,

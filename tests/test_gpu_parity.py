@@ -412,7 +412,7 @@ def test_ordered_tiles_variant(ra, oracle_mod):
             p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
             for rep in range(3):
                 assert_parity(p.run_host(s["planes"], s["cam_pos"]), want, f"ordered n={n} rep={rep}")
-    s = ra.scene.make_scene(3, n=120_000)
+    s = ra.scene.make_scene(3, n=40_000)  # 157 tiles: still the ticketed kernel (larger ordered launches are not recorded as graphs)
     want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
     with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2, ordered_tiles=True) as p:
         p.set_mesh_table(s["meshes"])

@@ -627,7 +627,7 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
     dev = torch.device("cuda", 0)
     # launches of up to 4 096 tiles have no scan launch (the last launch sums the earlier tiles' pairs itself): 1 200 003 instances
     # take the scan, and so does 70 001 with the switch forced (a partial last group of 64 tiles)
-    for n in ((1, 255, 4_097, 70_001, -70_001) if min_tiles == "0" else (131_072, 131_073, 1_200_003)):
+    for n in ((1, 255, 4_097, 70_001, -70_001) if min_tiles == "0" else (40_960, 40_961, 131_073, 1_200_003)):
         if n < 0:
             n = -n
             monkeypatch.setenv("MIP_TUNE_EMIT_SELF_PREFIX_TILES", "0")
@@ -644,7 +644,7 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
                 got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5)
                 from helpers import assert_parity
                 assert_parity(got, want, f"three-pass n={n} rep={rep}")
-            expect_three = 2 if (min_tiles == "0" or (n + 255) // 256 > 512) else 0
+            expect_three = 2 if (min_tiles == "0" or (n + 255) // 256 > 160) else 0
             assert p.timings()["three_pass_frames"] == expect_three, (n, p.timings()["three_pass_frames"])
             body = torch.zeros(wire_body_bytes(n) // 4, dtype=torch.int32, device=dev)
             scal = torch.zeros(8, dtype=torch.int32, device=dev)
