@@ -9,11 +9,12 @@
 namespace mip {
 
 // A frame in ordered-tiles mode (MIP_CFG_ORDERED_TILES, or after a stalled frame) must not depend on the order workgroups
-// start in. Large launches do that with three launches none of which waits for another workgroup (instance_kernel.hpp,
-// "the prefix without any wait"):
+// start in. Launches above 160 tiles do that with two or three launches none of which waits for another workgroup
+// (instance_kernel.hpp, "the prefix without any wait"):
 //   1  the frame kernel WITHOUT commands (KernelArgs.tile_agg_out): matrices, world boxes, TLAS rows, the visibility bitmap, and
-//      per tile the pair {emitted commands, sum of index_len}, summed per group of kTileGroup tiles;
-//   2  mip_tile_scan_kernel: exclusive prefixes of the group sums, and the totals (draw_count, index total);
+//      per tile the pair {emitted commands, sum of index_len};
+//   2  (above kEmitSelfPrefixTiles tiles only) mip_tile_scan_kernel: the pairs summed per group of kTileGroup tiles, exclusive
+//      prefixes of the group sums, and the totals (draw_count, index total);
 //   3  this kernel: per tile, the commands of compact_draw_stream.comp / cull_pass (cull_pipeline.rs:534-577) again from what
 //      launch 1 left — visible(i) is bit i of the bitmap, the LOD is pick_lod of the same positions (helpers.rs:3-11, the
 //      frame kernel's expression), index_len / vertex_offset come from the mesh table — at the positions the prefix gives.
