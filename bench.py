@@ -240,18 +240,18 @@ def cpu_baseline(scene_dict, seconds):
     }
 
 
-def make_pipe(renderer_amd, s, local_rank, stream=None, frames=1):
+def make_pipe(renderer_amd, s, local_rank, stream=None, frames=1, ordered_tiles=False):
     p = renderer_amd.InstancePipeline(max_instances=s["n"], max_meshes=len(s["meshes"]), device=local_rank,
-                                      stream=stream, frames_in_flight=frames)
+                                      stream=stream, frames_in_flight=frames, ordered_tiles=ordered_tiles)
     p.set_mesh_table(s["meshes"])
     p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
     return p
 
 
-def serialized_leg(torch, renderer_amd, make_frame, s, device, local_rank, stream, steps, warmup, samples):
+def serialized_leg(torch, renderer_amd, make_frame, s, device, local_rank, stream, steps, warmup, samples, ordered_tiles=False):
     """SURVEY.md §8(d) on scene `s`: one frame in flight on `stream`, HIP-event samples."""
     n = s["n"]
-    p = make_pipe(renderer_amd, s, local_rank, stream=stream)
+    p = make_pipe(renderer_amd, s, local_rank, stream=stream, ordered_tiles=ordered_tiles)
     o = DeviceOutputs(torch, n, device)
     torch.cuda.synchronize()
     prepared = p.prepare_outputs(**o.kwargs())
@@ -746,6 +746,13 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
         torch, renderer_amd, make_frame, scene.make_scene(3, all_visible=True), device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES)))
     guarded("mixed_10m_one_gpu_serialized", lambda: leg_summary(serialized_leg(
         torch, renderer_amd, make_frame, scene.make_scene(4), device, local_rank, stream, 5, 5, 20)))
+    # the mode for a GPU shared with other spin-waiting compute (MIP_CFG_ORDERED_TILES: no reliance on dispatch order; also what a
+    # context runs in after a stalled frame): wait-free launches instead of the one-pass kernel
+    guarded("mixed_1m_ordered_tiles_serialized", lambda: dict(leg_summary(serialized_leg(
+        torch, renderer_amd, make_frame, s3, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)),
+        note="MIP_CFG_ORDERED_TILES: frame kernel without commands + commands from the visibility bitmap (DESIGN.md section 14.8)"))
+    guarded("damaged_helmet_100k_ordered_tiles_serialized", lambda: leg_summary(serialized_leg(
+        torch, renderer_amd, make_frame, s2, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)))
     # next-tier rows (not the headline)
     guarded("triangle_cull_100k", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, not args.no_cpu_baseline))
     guarded("triangle_cull_100k_strips", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, False, ordering="strips"))
