@@ -29,6 +29,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mip_abi_version() == 3
+    # a pure function of the ABI (no device): the bits a packed wire record leaves for the instance index — the library's
+    # answer, the Python mirror's and the header's wording (31 - ceil(log2(n_meshes))) agree
+    from renderer_amd.pipeline import wire_index_bits
+    for m in (0, 1, 2, 3, 4, 5, 63, 64, 65, 1023, 1024, 1025, 1 << 20, (1 << 31) - 1, 1 << 31, (1 << 32) - 1):
+        want = 31 - max(0, min(31, (m - 1).bit_length() if m > 1 else 0))
+        assert lib.mip_wire_index_bits(m) == wire_index_bits(m) == want, m
 
 
 def test_struct_layouts_match_header():
