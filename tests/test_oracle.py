@@ -140,6 +140,36 @@ def test_lod_squared_distance_threshold_equivalence():
             assert bool(np.sqrt(special) > np.float32(10.0)) == bool(special > thr)
 
 
+def test_plane_test_without_the_subtraction():
+    """The multi-view kernel evaluates the frustum test `sd - e > 0` (cull_pipeline.rs:108-119) as `sd > e`. With subnormals
+    kept (the build's mode, and numpy's) the two agree for every pair of floats: a difference that underflows is exact, so its
+    sign is the comparison's; inf - inf and NaN are false on both sides. Checked on neighbours over every exponent, subnormals,
+    zeros, infinities, NaNs and random bit patterns."""
+    rng = np.random.default_rng(11)
+    base = []
+    for e in list(range(-149, 128, 2)) + [-126, -127, 127]:
+        v = np.float32(np.ldexp(1.0, e))
+        for frac in (1.0, 1.0000001, 1.5, 1.9999999):
+            base.append(np.float32(v * np.float32(frac)))
+    base = np.array(base + [0.0, np.inf, np.nan, 1e-45, 1.1754942e-38, 1.1754944e-38, 3.4028235e38], np.float32)
+    base = np.concatenate([base, -base])
+    sd, e = [], []
+    with np.errstate(all="ignore"):
+        for v in base:
+            near = [v]
+            up, dn = v, v
+            for _ in range(4):
+                up = np.nextafter(up, np.float32(np.inf)); dn = np.nextafter(dn, np.float32(-np.inf))
+                near += [up, dn]
+            for x in near:
+                sd.append(np.float32(x)); e.append(v)
+                sd.append(v); e.append(np.float32(x))
+        bits = rng.integers(0, 2**32, 400_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        sd = np.concatenate([np.array(sd, np.float32), bits[:200_000], rng.standard_normal(100_000).astype(np.float32)])
+        e = np.concatenate([np.array(e, np.float32), bits[200_000:], np.abs(rng.standard_normal(100_000)).astype(np.float32)])
+        assert np.array_equal((sd - e) > np.float32(0), sd > e)
+
+
 def test_ndc_comparison_without_division():
     """The triangle kernel tests RN(x/w) > 1 as x*sgn(w) > |w| (and < -1 as x*sgn(w) < -|w|) instead of
     dividing. Check the equivalence against float32 divisions on the cases where it could break: x within a
