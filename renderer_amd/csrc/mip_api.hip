@@ -894,11 +894,14 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
   ctx->next_slot = (ctx->next_slot + 1) % (uint32_t)ctx->slots.size();
   hipStream_t stream = sl.stream;
   const bool alone = !ctx->pending_async;  // nothing else of this context is in flight: an error seen at the end of a synchronous frame is its own
-  sl.replay.issued += 1;
-  sl.replay.frame = *frame;
-  sl.replay.out = *out;
-  sl.replay.skinned = skinned;
-  sl.replay.palette = palette;
+  const uint32_t this_slot = ctx->last_slot;
+  if (async) {  // on record until the streams are drained (a synchronous frame is repeated from its live arguments instead: below)
+    sl.replay.issued += 1;
+    sl.replay.frame = *frame;
+    sl.replay.out = *out;
+    sl.replay.skinned = skinned;
+    sl.replay.palette = palette;
+  }
 
   const uint32_t n = ctx->n;
   const uint32_t words = (n + 31u) / 32u;
@@ -1140,19 +1143,26 @@ static int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutput
     ctx->timings.total_kernel_ms += ms;
   }
   int32_t rc = check_device_error(ctx);
-  if (alone) {
-    if (rc == MIP_ERR_TIMEOUT) rc = recover_from_timeout(ctx, rc);
-    if (!ctx->recovering) {
-      for (auto& s2 : ctx->slots) s2.replay.issued = 0;
-      ctx->replay_blocked = false;
+  if (alone && !ctx->recovering) {
+    // a synchronous frame with nothing else in flight: a stall was its own, and nobody can have consumed its outputs yet — the
+    // context has switched modes in check_device_error, the frame is issued once more from the caller's (still live) arguments
+    constexpr uint32_t kRecoverable = mip::kErrTimeout | mip::kErrPartsTimeout;
+    if (rc == MIP_ERR_TIMEOUT && (ctx->last_error_bits & kRecoverable) && !(ctx->last_error_bits & ~kRecoverable)) {
+      ctx->recovering = true;
+      ctx->next_slot = this_slot;
+      rc = run_frame(ctx, frame, out, skinned, palette);
+      ctx->recovering = false;
+      if (rc == MIP_OK) ctx->timings.timeout_recoveries += 1;
     }
+    for (auto& s2 : ctx->slots) s2.replay.issued = 0;
+    ctx->replay_blocked = false;
   }
   return rc;
 }
 
 // A frame kernel's bounded wait has expired (kErrTimeout: the context has just switched itself to ordered tiles; kErrPartsTimeout: the
-// parts kernel of the per-triangle stage is off from now on). The frames that were in flight are on record, one per frame slot:
-// they are issued again — in the mode that cannot stall — and the caller gets their results instead of MIP_ERR_TIMEOUT (counted in
+// parts kernel of the per-triangle stage is off from now on), seen by mip_wait. The ASYNCHRONOUS frames that were in flight are on
+// record, one per frame slot (their outputs are device memory the caller keeps alive until mip_wait): they are issued again — in the mode that cannot stall — and the caller gets their results instead of MIP_ERR_TIMEOUT (counted in
 // MipTimings.timeout_recoveries; the 0.5 s of the expired wait are the price). Not possible, and the error is reported as before,
 // when a slot carried more than one frame since the streams were last drained, or when something was in flight that is not on
 // record or has side effects elsewhere: a recorded round of mip_run_many, a multi-view or sharded frame (collective), a merge (it
@@ -1175,7 +1185,7 @@ static int32_t recover_from_timeout(MipContext* ctx, int32_t rc) {
     MipContext::FrameSlot::Replay r = ctx->slots[k].replay;  // a copy: run_frame overwrites the record
     if (r.issued != 1) continue;
     ctx->next_slot = (uint32_t)k;
-    if (r.out.flags & MIP_OUT_DEVICE) r.out.flags |= MIP_OUT_ASYNC;  // all slots first, one drain below (host outputs are synchronous by nature)
+    // (records are asynchronous device-output frames: all slots first, one drain below)
     again = run_frame(ctx, &r.frame, &r.out, r.skinned, r.palette);
   }
   ctx->next_slot = keep_next;
