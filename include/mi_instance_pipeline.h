@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIP_ABI_VERSION 3u
+#define MIP_ABI_VERSION 4u
 
 /* ---- status codes (0 = success, negative = error; like VkResult in vma) ---- */
 #define MIP_OK 0
@@ -43,32 +43,22 @@ extern "C" {
 #define MIP_ERR_CAPACITY (-4)         /* more instances / meshes than the context was created for */
 #define MIP_ERR_DEVICE (-5)           /* a HIP runtime call failed; see mip_last_error */
 #define MIP_ERR_NOT_READY (-6)        /* run before instances / mesh table were set */
-#define MIP_ERR_TIMEOUT (-7)          /* a bounded in-kernel wait expired; outputs are invalid. Reported only when the library could
-                                       * not issue the affected frames again itself: it does that (ordered tiles from then on,
-                                       * MipTimings.timeout_recoveries) whenever every frame slot carried at most one frame since
-                                       * the last mip_wait and nothing unrepeatable was in flight — a recorded mip_run_many
-                                       * round, a multi-view or sharded frame, a merge, an external-semaphore operation, an
-                                       * asynchronous frame on a caller-owned stream (MipConfig.stream: work the caller queued
-                                       * behind the frame has already consumed the invalid result) */
+#define MIP_ERR_TIMEOUT (-7)          /* a stream-ordered wait for an EXTERNAL semaphore expired (10 s; mip_wait_external). No kernel
+                                       * of this library waits for another workgroup to run — a tile whose predecessor has not
+                                       * published computes that predecessor's aggregate itself (MipTimings.prefix_helps) — so
+                                       * a frame cannot time out, whatever order the hardware starts workgroups in and
+                                       * whatever else shares the GPU. (ABI <= 3 reported expired in-kernel waits here.) */
 
 /* ---- MipConfig.flags ---- */
 #define MIP_CFG_TIMING 0x1u /* bracket every kernel with hipEvents (mip_get_timings) */
-#define MIP_CFG_ORDERED_TILES 0x2u /* hand tile numbers out from a counter instead of taking the workgroup index.
-                                     * The default relies on the hardware starting a launch's workgroups in index
-                                     * order (true for a launch that has the chip to itself; NOT guaranteed by HIP,
-                                     * and seen to fail when spin-waiting launches of several PROCESSES shared one
-                                     * GPU: such a frame's bounded wait — 0.5 s and 2^18 polls — expires, the context
-                                     * switches itself to this mode for good and issues the frame again, or reports
-                                     * MIP_ERR_TIMEOUT when it cannot: see there). With this flag the cross-tile prefix cannot stall
-                                     * whatever order workgroups start in, other tenants included. Small launches (up to
-                                     * 512 tiles = 131 072 instances) take their tile numbers from a counter — one
-                                     * returning atomic on ONE address per workgroup, ~11 ns each and serialised: 9.7
-                                     * instead of 5.6 us at 100 k instances; larger ones run as THREE launches none of
-                                     * which waits for another workgroup (the frame kernel without commands, a scan of its
-                                     * per-tile counts, the commands from the visibility bitmap): 26.0 instead of
-                                     * 18.6 us at 1 M instances, 214 instead of 180 at 10 M (tickets: 56 / 464;
-                                     * DESIGN.md section 14.8). Set it when the GPU is shared with other compute that waits
-                                     * on the device. mip_run_views runs one frame per view in this mode. */
+#define MIP_CFG_ORDERED_TILES 0x2u /* accepted and ignored since ABI 4. Up to ABI 3 the default frame kernel relied on the
+                                     * hardware starting a launch's workgroups in index order (not guaranteed by HIP, and seen
+                                     * to fail when several processes shared one GPU) and this flag selected slower modes that
+                                     * did not (tickets: 56 us at 1 M instances; three wait-free launches: 26 us, against 18.5).
+                                     * Now EVERY launch is independent of the order workgroups start in: the one-hop look-up of
+                                     * a tile's prefix polls a bounded number of times and then computes what is missing itself
+                                     * (decoupled look-back with a fallback; renderer_amd/csrc/instance_kernel.hpp). In-order
+                                     * dispatch is a performance property only. */
 
 /* ---- MipOutputs.flags ---- */
 #define MIP_OUT_HOST 0x0u   /* output pointers are host memory (copied back, synchronous) */
@@ -77,7 +67,7 @@ extern "C" {
                               * OTHER streams for those buffers (a clear, a previous reader) is not waited for —
                               * order it with an event / synchronize, or hand the library that stream */
 #define MIP_OUT_ASYNC 0x2u  /* with MIP_OUT_DEVICE: return after enqueue; pair with mip_wait */
-#define MIP_OUT_WIRE 0x4u   /* with MIP_OUT_DEVICE: draw_cmds receives the list in the WIRE form below (8.06 B per
+#define MIP_OUT_WIRE 0x4u   /* with MIP_OUT_DEVICE and a 16-BYTE ALIGNED draw_cmds: it receives the list in the WIRE form below (8.06 B per
                               * command instead of 20) — what a rank sends through the all-gather; draw_count and
                               * draw_index_total as usual. Not with culled_index_buffer (the wire form carries no
                               * indexCount: it is the mesh table's). mip_merge_wire_lists expands it again. */
@@ -198,11 +188,13 @@ typedef struct MipTimings {
   uint64_t graph_records;     /* times it had to record a new set of graphs */
   uint64_t sharded_retries;   /* sharded frames whose tightened chunk overflowed and were re-gathered at full capacity */
   uint64_t sharded_bytes_sent; /* bytes this rank contributed to the last sharded frame's all-gather */
-  uint64_t three_pass_frames;  /* ordered-tiles frames that ran as three wait-free launches (large launches) instead of one ticketed one */
+  uint64_t prefix_helps;      /* tile aggregates a WAITING tile computed itself because their owner had not published within the
+                                 patient polls (see MIP_ERR_TIMEOUT): 0 on a GPU this context has to itself; non-zero means the
+                                 hardware started workgroups out of order or another tenant held compute units — results are
+                                 the same either way. Cumulative since create / mip_reset_timings */
   uint64_t general_launches;  /* frames launched with the kernel that carries the literal path for non-finite
                                  inputs (some resident instance failed the upload-time finite test, or a skinned frame) */
-  uint64_t timeout_recoveries; /* times a bounded in-kernel wait expired and the library issued the affected frame(s) again itself
-                                 (see MIP_ERR_TIMEOUT): the caller saw MIP_OK and valid outputs */
+  uint64_t reserved0;         /* (ABI 3: timeout_recoveries) */
 } MipTimings;
 
 /* Chunk header used by mip_merge_draw_lists: what each rank contributes to the
@@ -378,7 +370,9 @@ int32_t mip_run_skinned(MipContext* ctx, const MipFrame* frame, const MipOutputs
 int32_t mip_run_views(MipContext* ctx, const MipFrame* frames, const MipOutputs* outs, uint32_t n_views);
 
 /* Block until everything enqueued by this context has finished; reports a
- * deferred MIP_ERR_TIMEOUT / MIP_ERR_DEVICE of an async run. */
+ * deferred error of an async run (MIP_ERR_CAPACITY, MIP_ERR_DEVICE, MIP_ERR_TIMEOUT of an external semaphore).
+ * Frames ordered by external semaphores still need this call at a bounded cadence (e.g. every
+ * frames_in_flight frames): it is where their errors surface. */
 int32_t mip_wait(MipContext* ctx);
 
 /* Merge `n_chunks` shard draw lists (each: MipShardHeader followed by its commands,

@@ -110,9 +110,9 @@ class MipTimings(C.Structure):
         ("graph_records", C.c_uint64),
         ("sharded_retries", C.c_uint64),
         ("sharded_bytes_sent", C.c_uint64),
-        ("three_pass_frames", C.c_uint64),
+        ("prefix_helps", C.c_uint64),
         ("general_launches", C.c_uint64),
-        ("timeout_recoveries", C.c_uint64),
+        ("reserved0", C.c_uint64),
     ]
 
 

@@ -1,0 +1,195 @@
+// frame_plan.hpp — WHICH kernels a frame runs, in which instantiation, over which grid, and what scratch they need: a
+// PURE function of the context's state and of what the caller asked for. No HIP, no allocation, no I/O — so the
+// decision table of the library can be enumerated on a CPU, under the sanitizers, without a GPU
+// (tests/test_frame_plan.py builds tests/frame_plan_check.cpp with gcc -fsanitize=address,undefined). api_frame.hip
+// executes the plan it gets; it takes no decision of its own.
+//
+// Replaces the mode selection that rounds 1-3 had interleaved with the launches inside run_frame (mip_api.hip).
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/mi_instance_pipeline.h"
+
+namespace mip {
+
+constexpr uint32_t kPlanTile = 256;               // = kTile (instance_kernel.hpp; static_assert in api_frame.hip)
+constexpr uint32_t kPlanTriParts = 16;            // = kTriParts
+constexpr uint32_t kPlanTriPartMaxT = 8;          // = kTriPartMaxT
+
+// What the decision depends on: resident state + tuning knobs of the context.
+struct PlanState {
+  uint32_t n = 0;                  // resident instances
+  uint32_t n_meshes = 0;
+  uint32_t max_instances = 0;
+  uint32_t cu_count = 256;
+  uint32_t frame_slots = 1;        // MipConfig.frames_in_flight
+  bool have_instances = false, have_meshes = false, have_geometry = false;
+  bool nonfinite = false;          // the upload-time census found an instance that needs the fall-back arithmetic tiers
+  bool force_general = false;      // MIP_TUNE_FORCE_GENERAL
+  int force_order = 0;             // MIP_TUNE_ORDER: 1 | 3, 0 = by launch size
+  uint32_t tri_block_threads = 0;  // MIP_TUNE_TRI_BLOCK_THREADS: 256 | 512 | 1024, 0 = by instance count
+  uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
+  uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel, 0 = off
+  uint32_t max_lod_tris = 0;       // largest triangle count of LOD 0 / LOD 1 over the mesh table
+  uint32_t n_joints = 0;           // skinned frames
+};
+
+// What the caller asked for (MipOutputs, decoded) + how the frame was entered.
+struct PlanRequest {
+  bool model = false, bitmap = false, cmds = false, count = false, index_total = false, aabb = false, tlas = false;
+  bool triangles = false;          // culled_index_buffer set
+  bool skinned = false;            // mip_run_skinned
+  uint32_t flags = 0;              // MIP_OUT_*
+  uintptr_t cmds_address = 0;      // draw_cmds as an integer (alignment rules of the wire forms)
+};
+
+enum class TriangleKernel : uint8_t { none, parts, block, waves };
+enum class Recompact : uint8_t { none, single, wide };
+
+struct LaunchPlan {
+  int32_t status = MIP_OK;         // MIP_OK, or the error the frame must be refused with ...
+  const char* why = "";            // ... and its message (static text; api_frame.hip adds the numbers)
+  bool device_out = false, async = false;
+  bool empty = false;              // no resident instances: counts are zeroed, nothing launches
+  // frame kernel (rows a-1 .. a-7)
+  uint32_t n_tiles = 0;            // grid of the frame kernel
+  int order = 1;                   // kOrder: 1 = stores first (mip_api/api_frame unit), 3 = commands first (stages_tu unit)
+  bool general = false;            // kGeneral: the kernel that carries the fall-back arithmetic tiers
+  bool box_override = false;       // kBoxOverride: skinned frame
+  int wire = 0;                    // kWire: 0 | 1 | 2 = packed
+  uint32_t group_shift = 4;        // log2(tiles per level-1 group)
+  bool uses_prefix_state = false;  // the launch emits commands: it needs a fresh tag
+  // extension: skinning kernel in front of the frame kernel
+  bool skin = false;
+  uint32_t skin_blocks = 0;
+  // row f-1: per-triangle stage behind it
+  TriangleKernel tri = TriangleKernel::none;
+  uint32_t tri_threads = 0, tri_blocks = 0;
+  bool tri_reset_ticket = false;   // the wave-per-command kernel pulls commands from a counter the host zeroes
+  Recompact recompact = Recompact::none;
+  uint32_t recompact_blocks = 0;
+  // scratch the slot must own before the launches
+  bool need_staging = false;       // host outputs: device staging + copy-back
+  bool need_tri_scratch = false;   // list before re-compaction, source offsets, block counts
+  bool need_part_status = false;   // granules of the parts kernel
+  bool need_skin_box = false;      // per-instance posed box
+};
+
+inline uint32_t plan_tiles_for(uint32_t n) { return (n + kPlanTile - 1u) / kPlanTile; }
+
+inline int plan_wire_form(uint32_t out_flags) { return (out_flags & MIP_OUT_WIRE) ? ((out_flags & MIP_OUT_WIRE_PACKED) ? 2 : 1) : 0; }
+
+// mip_wire_index_bits, restated here so that the plan has no link-time dependency (test_abi.py checks both against the header's formula)
+inline uint32_t plan_wire_index_bits(uint32_t n_meshes) {
+  uint32_t mesh_bits = 0;
+  while (mesh_bits < 31u && (1ull << mesh_bits) < n_meshes) ++mesh_bits;
+  return 31u - mesh_bits;
+}
+
+inline LaunchPlan plan_refuse(int32_t status, const char* why) {
+  LaunchPlan p;
+  p.status = status;
+  p.why = why;
+  return p;
+}
+
+// The whole decision. Order of the checks = order of the error messages round 3's validate_run produced.
+inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
+  if (!st.have_instances || !st.have_meshes) return plan_refuse(MIP_ERR_NOT_READY, "instances or mesh table not set");
+  if (rq.cmds != rq.count) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "draw_cmds and draw_count go together");
+  if (rq.index_total && !rq.cmds) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "draw_index_total needs draw_cmds");
+  const bool device_out = (rq.flags & MIP_OUT_DEVICE) != 0;
+  if ((rq.flags & MIP_OUT_ASYNC) && !device_out) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_ASYNC needs MIP_OUT_DEVICE");
+  if (rq.flags & MIP_OUT_WIRE) {
+    if (!device_out || !rq.cmds) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs MIP_OUT_DEVICE and draw_cmds");
+    if (rq.triangles) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE cannot carry the per-triangle stage's indexCount");
+    if (rq.skinned) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE is not available for skinned frames");
+    if (st.n_meshes > 0x7fffffffu) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs mesh ids below 2^31");
+    if (rq.cmds_address & 15u) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE needs a 16-byte aligned draw_cmds (block headers are 16-byte stores)");
+    if ((rq.flags & MIP_OUT_WIRE_PACKED) && (uint64_t)st.n > (1ull << plan_wire_index_bits(st.n_meshes)))
+      return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE_PACKED: the instances do not fit the index bits the mesh table leaves");
+  } else if (rq.flags & MIP_OUT_WIRE_PACKED) {
+    return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "MIP_OUT_WIRE_PACKED goes with MIP_OUT_WIRE");
+  }
+  if (rq.triangles) {
+    if (!device_out) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs MIP_OUT_DEVICE");
+    if (rq.skinned) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "the per-triangle stage does not skin vertices");
+    if (!st.have_geometry) return plan_refuse(MIP_ERR_NOT_READY, "culled_index_buffer needs mip_set_geometry");
+    if (!rq.model || !rq.cmds) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "culled_index_buffer needs model and draw_cmds");
+  }
+  if (rq.tlas && !device_out) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "tlas_instances needs MIP_OUT_DEVICE");
+  if (rq.skinned && !device_out) return plan_refuse(MIP_ERR_INVALID_ARGUMENT, "mip_run_skinned needs MIP_OUT_DEVICE outputs");
+  if (rq.skinned && (st.n_joints == 0 || st.n_joints > 32u)) return plan_refuse(MIP_ERR_NOT_READY, "skeleton or poses not set for the resident instances");
+
+  LaunchPlan p;
+  p.device_out = device_out;
+  p.async = device_out && (rq.flags & MIP_OUT_ASYNC) != 0;
+  p.need_staging = !device_out;
+  p.need_tri_scratch = rq.triangles;
+  p.need_skin_box = rq.skinned;
+  const uint32_t n = st.n;
+  if (n == 0) {
+    p.empty = true;
+    return p;
+  }
+  p.n_tiles = plan_tiles_for(n);
+  // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of workgroups
+  // (8 per CU: every tile is ramp or tail), stores-first once there is a steady state. Measured on MI355X
+  // (profiles/r02_order*.txt): order 3 ahead below ~0.8 M instances, order 1 ahead from ~1 M.
+  p.order = p.n_tiles <= st.cu_count * 14u ? 3 : 1;
+  if (st.force_order == 1 || st.force_order == 3) p.order = st.force_order;
+  p.box_override = rq.skinned;
+  p.general = rq.skinned || st.nonfinite || st.force_general;  // a per-instance box may be non-finite
+  p.wire = device_out ? plan_wire_form(rq.flags) : 0;
+  p.group_shift = p.n_tiles <= 512u ? 4u : (p.n_tiles <= 2048u ? 5u : 6u);
+  p.uses_prefix_state = rq.cmds;
+  if (rq.skinned) {
+    p.skin = true;
+    const uint32_t per_block = 4u * (64u / st.n_joints);
+    p.skin_blocks = (n + per_block - 1u) / per_block;
+  }
+  if (rq.triangles) {
+    // The command count lives on the device; the instance count bounds it.
+    //  - tiny frames (the reference's own regime): every command cut into 16 parts, one work item each — only while the
+    //    context runs one frame at a time (the grid is sized to be resident as a whole; nothing DEPENDS on that any more,
+    //    but two half-resident launches would spend their time helping each other);
+    //  - up to tri_block_max instances: one workgroup per command; 1024 / 512 / 256 threads by frame size (measured,
+    //    DamagedHelmet entry, frame time in us at 256 / 512 / 1024 threads: 200 instances 35 / 28 / 27, 1000: 60 / 49 / 56,
+    //    2000: 72 / 66 / 73, 4000: 85 / 88 / 108, 20 k: 266 / 324 / 347);
+    //  - above: one wave per command (100 k: 1.15 vs 1.21 ms), commands pulled from a counter.
+    const bool parts = st.tri_parts_max && n <= st.tri_parts_max && !st.tri_block_threads && st.frame_slots == 1 &&
+                       st.max_lod_tris <= kPlanTriParts * 256u * kPlanTriPartMaxT;
+    if (parts) {
+      p.tri = TriangleKernel::parts;
+      p.tri_threads = 256;
+      p.need_part_status = true;
+      uint32_t blocks = n * kPlanTriParts;
+      const uint32_t max_blocks = st.cu_count * 4u;  // resident as a whole at this kernel's register budget (4 waves per SIMD)
+      p.tri_blocks = blocks > max_blocks ? max_blocks : blocks;
+    } else if (n <= st.tri_block_max) {
+      p.tri = TriangleKernel::block;
+      p.tri_threads = st.tri_block_threads ? st.tri_block_threads : (n <= 768u ? 1024u : (n <= 3072u ? 512u : 256u));
+      const uint32_t per_cu = 2u * (1024u / p.tri_threads);
+      uint32_t blocks = n < st.cu_count * per_cu ? n : st.cu_count * per_cu;
+      p.tri_blocks = blocks ? blocks : 1u;
+    } else {
+      p.tri = TriangleKernel::waves;
+      p.tri_threads = 256;
+      p.tri_reset_ticket = true;
+      uint32_t blocks = (n + 3u) / 4u;
+      const uint32_t max_blocks = st.cu_count * 8u;
+      p.tri_blocks = blocks > max_blocks ? max_blocks : blocks;
+    }
+    if (n <= st.tri_block_max) {
+      p.recompact = Recompact::single;
+      p.recompact_blocks = 1;
+    } else {  // many commands: counts per 1024, one block scans them, scatter
+      p.recompact = Recompact::wide;
+      p.recompact_blocks = (n + 1023u) / 1024u;
+    }
+  }
+  return p;
+}
+
+}  // namespace mip

@@ -46,8 +46,6 @@ namespace mip {
 constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
-constexpr uint32_t kTileGroup = 64;       // ordered tiles, large launches: tiles per group of the scan launch (see "the prefix without any wait")
-constexpr uint32_t kEmitSelfPrefixTiles = 4096;  // ... launches of at most this many tiles (1 M instances) have no scan launch: emit_kernel.hpp
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
 
 // Device-side mesh entry: what the kernel needs of MipMesh, 32 B, two 16-B gathers.
@@ -84,17 +82,13 @@ struct KernelArgs {
   float* world_aabb;            // n*6 or null
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
-  uint32_t* tile_ticket;        // ordered-tiles variant only: next tile number, 0 between launches
-  uint2* tile_agg_out;          // ordered-tiles variant only, large launches (launch 1 of 3, cmds == null): the tile's {count, sum index_len}
-                                // goes here; tile = blockIdx.x, nothing is published or waited for; mip_tile_scan_kernel and
-                                // mip_emit_commands_kernel (emit_kernel.hpp) turn the pairs and the visibility bitmap into the list
   const float* box_override;    // n*8 or null: per-instance mesh-space box {min xyz, -, max xyz, -} that replaces the mesh table's (skinned instances)
   unsigned long long* status0;  // level 0: one tagged granule per tile
   unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
   uint32_t groups_cap;
   uint32_t group_shift;         // log2(tiles per group), <= 6
-  uint32_t* error_flag;         // host-mapped
+  uint32_t* error_flag;         // host-mapped: error words + the help counter
   uint32_t n;
   uint32_t n_tiles;
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
@@ -115,6 +109,9 @@ struct KernelArgs {
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* stamps;  // diagnostic build only: 8 realtime stamps per tile
   uint32_t debug_skip_publish_tile;  // diagnostic build only: tile index + 1 that never publishes (0 = off)
+  uint32_t debug_tile_mult, debug_tile_add;  // diagnostic build only: tile = (blockIdx.x * mult + add) % n_tiles, a permutation of the
+                                             // tiles (mult coprime to n_tiles; mult = add = n_tiles - 1 reverses them): the launch must
+                                             // give the same bytes in ANY order workgroups start in (0 = off)
 #endif
 };
 
@@ -140,13 +137,14 @@ constexpr float kLodDistSqThreshold = 100.00000762939453125f;  // 100 + 2^-17
 // Device -> host error word(s), host-mapped memory. Every kind of error has a word of its own (plain stores from
 // different kernels of one frame must not overwrite each other: a timeout in the shard kernel followed by an
 // overflow seen by the merge kernel are BOTH needed by the host); the host ORs the words together.
-constexpr uint32_t kErrTimeout = 1u;         // word 0: a bounded prefix wait of the instance / views kernel expired
+// (words 0 and 4 were the time-outs of the in-kernel waits of rounds 1-3; no kernel waits on another workgroup any more:
+//  resolve_prefix below)
 constexpr uint32_t kErrChunkOverflow = 2u;   // word 1: a gathered shard list is longer than the exchanged chunk
 constexpr uint32_t kErrIndexOverflow = 4u;   // word 2: culled_index_buffer too small
 constexpr uint32_t kErrWireRecord = 8u;      // word 3: a wire record names a mesh outside the table
-constexpr uint32_t kErrPartsTimeout = 16u;   // word 4: a bounded wait of the triangle parts kernel expired
 constexpr uint32_t kErrSemaphore = 32u;      // word 5: written by the HOST (a stream-ordered wait on an external semaphore expired)
 constexpr uint32_t kErrWords = 6;
+constexpr uint32_t kHelpCounterWord = 8;     // word 8 of the same block is not an error: it counts helped tiles (resolve_prefix)
 __device__ __forceinline__ void raise_error(uint32_t* error_flag, uint32_t bit) {
   __hip_atomic_store(error_flag + (31 - __builtin_clz(bit)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -449,14 +447,114 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
     __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A wait gives up (MIP_ERR_TIMEOUT) only when BOTH bounds are exceeded: 0.5 s of the 100 MHz realtime counter AND
-// 2^18 polls by this wave (each a memory round trip + s_sleep, >= ~1 us: at least a quarter of a second of RUNNING
-// time). The realtime bound alone expired spuriously when several processes shared the GPU and the hardware
-// scheduler kept this process's queue off the chip for long stretches (seen with 2-3 ranks of the bench on one
-// GPU over gloo): a wave that is not running is not stuck.
-constexpr unsigned long long kSpinTimeoutTicks = 50000000ull;
-constexpr uint32_t kSpinMinPolls = 1u << 18;
+// NO WAIT IN THIS LIBRARY DEPENDS ON ANOTHER WORKGROUP EVER RUNNING. A tile polls its predecessors' words a bounded
+// number of times (kPatientPolls: tens of microseconds, many times what a predecessor that IS running needs to
+// publish); a predecessor that still has not published — because the hardware has not started its workgroup yet,
+// because another tenant of the GPU holds the compute units it would run on, because a debugger holds it — is then not
+// waited for: the waiting wave computes that tile's aggregate ITSELF from the tile's inputs (`help`, supplied by the
+// kernel: the same loads and the same arithmetic the owner runs, so the same {count, sum}) and publishes the level-0
+// granule on the owner's behalf (idempotent: the owner stores the same 8 bytes later; only owners add to the level-1
+// accumulators, so those stay exact). This is decoupled look-back with a fallback: the launch makes progress in ANY
+// order the hardware starts workgroups in, with no ticket at the head of every workgroup (11 ns each, serialised) and
+// no second launch. In-order dispatch — what an idle chip does — is now a performance property (no helps), not a
+// correctness assumption. Helps are counted in a host-mapped word (MipTimings.prefix_helps).
+// Round 3 and before: the same polls bounded at 0.5 s, then MIP_ERR_TIMEOUT, a ticketed re-issue and a recovery path.
+constexpr uint32_t kPatientPolls = 64;
 constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
+
+template <class A>
+__device__ __forceinline__ bool granule_ready(const A& a, unsigned long long g) {
+  return (((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch;
+}
+
+// Σ aggregates of tiles [first, first + count), count <= 64, run by one whole wave: granules where they are published,
+// `help` where they are not. `spread` rotates the order in which missing tiles are taken so that several waiting waves
+// help different tiles first (each publishes what it computed; the others then find it).
+template <class A, class Help>
+__device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, uint32_t count, uint32_t lane, uint32_t spread,
+                                                  Help& help, uint32_t& c, uint32_t& s) {
+  // (c and s are wave-uniform; nothing per lane stays alive across a help: the cold path must fit the hot path's registers)
+  unsigned long long missing;
+  {
+    uint32_t myc = 0, mys = 0;
+    bool have = lane >= count;
+    if (!have) {
+      const unsigned long long g = status_load(&a.status0[first + lane]);
+      if (granule_ready(a, g)) { have = true; myc = (uint32_t)g & ((1u << kTileCountBits) - 1u); mys = (uint32_t)(g >> 32); }
+    }
+    missing = __ballot(!have);
+    c += wave_sum(myc);
+    s += wave_sum(mys);
+  }
+  const uint32_t rot = spread & 63u;
+#pragma nounroll
+  while (missing) {  // wave-uniform
+    const unsigned long long turned = rot ? ((missing >> rot) | (missing << (64u - rot))) : missing;
+    const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__builtin_ctzll(turned) + rot) & 63u));
+    const uint32_t u = first + pick;
+    const unsigned long long g = status_load(&a.status0[u]);  // somebody may have published it meanwhile (uniform address)
+    uint32_t uc = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)g & ((1u << kTileCountBits) - 1u)));
+    uint32_t us = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(g >> 32));
+    if (!granule_ready(a, g)) {  // uniform
+      const unsigned long long agg = help(u);  // {sum : 32 | count : 32}, wave-uniform
+      uc = (uint32_t)agg;
+      us = (uint32_t)(agg >> 32);
+      if (lane == 0u) {
+        __hip_atomic_store(&a.status0[u], ((unsigned long long)us << 32) | ((unsigned long long)a.epoch << kTileCountBits) | uc,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(a.error_flag + kHelpCounterWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    c += uc;
+    s += us;
+    missing &= ~(1ull << pick);
+  }
+}
+
+// The prefix of `tile` without waiting for anybody (cold path of resolve_prefix).
+template <class A, class Help>
+__device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile, uint32_t lane, Help& help,
+                                                                 uint32_t& base_count, uint32_t& base_sum) {
+  const uint32_t group = tile >> a.group_shift;
+  const uint32_t group_first = group << a.group_shift;
+  const uint32_t per_group = 1u << a.group_shift;
+  const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
+  uint32_t c = 0, s = 0;
+  sum_tiles_helping(a, group_first, tile - group_first, lane, tile, help, c, s);  // earlier tiles of the own group
+  // earlier groups: from the published start of group g_lo if there is one, else all of them
+  uint32_t lo = group > kLevel1Window ? group - kLevel1Window : 0u;
+  if (lo > 0u) {
+    const unsigned long long pc = status_load(&a.start1[2 * (size_t)lo]), ps = status_load(&a.start1[2 * (size_t)lo + 1]);
+    if ((uint32_t)(pc >> 32) == a.epoch && (uint32_t)(ps >> 32) == a.epoch) { c += (uint32_t)pc; s += (uint32_t)ps; }
+    else lo = 0u;
+  }
+#pragma nounroll
+  for (uint32_t gb = lo; gb < group; gb += 64u) {
+    const uint32_t gg = gb + lane;
+    const bool valid = gg < group;
+    unsigned long long open;
+    {
+      uint32_t myc = 0, mys = 0;
+      bool complete = false;
+      if (valid) {
+        const unsigned long long w = status_load(&acc[(size_t)gg * kAccStrideWords]);
+        complete = ((uint32_t)w >> kAccCountBits) == per_group;
+        if (complete) { myc = (uint32_t)w & ((1u << kAccCountBits) - 1u); mys = (uint32_t)(w >> 32); }
+      }
+      c += wave_sum(myc);
+      s += wave_sum(mys);
+      open = __ballot(valid && !complete);
+    }
+#pragma nounroll
+    while (open) {  // wave-uniform: groups some of whose tiles have not added yet — tile by tile
+      const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(open));
+      sum_tiles_helping(a, (gb + pick) << a.group_shift, per_group, lane, tile, help, c, s);
+      open &= ~(1ull << pick);
+    }
+  }
+  base_count = c;
+  base_sum = s;
+}
 
 // Run by one whole wave after publish_aggregate(tile). Returns the exclusive prefix of `tile`:
 //   prefix = start1[g_lo]  +  Σ acc1[g_lo .. g-1]  +  Σ status0[first tile of g .. tile-1]
@@ -465,16 +563,16 @@ constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators
 // entry read here is 64 groups = thousands of tiles back, i.e. long resolved, so the look-up
 // stays ONE round of <= 63 + 64 + 1 words for any N (without it every tile would read every
 // earlier group: quadratic, measured +100 us at 10 M instances).
-template <class A>
+// `help(u)`: the aggregate {sum : 32 | count : 32} of tile u computed from its inputs by the calling wave.
+template <class A, class Help>
 __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32_t lane,
-                                               uint32_t& base_count, uint32_t& base_sum) {
+                                               uint32_t& base_count, uint32_t& base_sum, Help help) {
   const uint32_t group = tile >> a.group_shift;
   const uint32_t group_first = group << a.group_shift;
   const uint32_t r = tile - group_first;  // earlier tiles of the own group (< 64)
   const uint32_t per_group = 1u << a.group_shift;
   const uint32_t g_lo = group > kLevel1Window ? group - kLevel1Window : 0u;
   const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   bool ok = true;
 
   // level 0: lane l < r reads the aggregate of tile group_first + l
@@ -492,7 +590,7 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
   for (;;) {
     if (!ready0) {
       const unsigned long long g = status_load(e0);
-      if ((((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch) {
+      if (granule_ready(a, g)) {
         ready0 = true;
         c += (uint32_t)g & ((1u << kTileCountBits) - 1u);
         s += (uint32_t)(g >> 32);
@@ -520,24 +618,22 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
     if (__all(all)) break;
-    if (++polls > kSpinMinPolls && __builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) {  // scalar: wave-uniform
+    if (__builtin_expect(++polls > kPatientPolls, 0)) {  // scalar: wave-uniform
       ok = false;
       break;
     }
     __builtin_amdgcn_s_sleep(1);
   }
-  if (ok) {
+  if (__builtin_expect(ok, 1)) {
     base_count = wave_sum(c);
     base_sum = wave_sum(s);
-    if (r == 0u && group > 0u && lane == 0u) {  // first tile of a group: publish the group's start
-      unsigned long long* p = &a.start1[2 * (size_t)group];
-      __hip_atomic_store(p, ((unsigned long long)a.epoch << 32) | base_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p + 1, ((unsigned long long)a.epoch << 32) | base_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   } else {
-    if (lane == 0) raise_error(a.error_flag, kErrTimeout);
-    base_count = 0;
-    base_sum = 0;
+    resolve_prefix_unaided(a, tile, lane, help, base_count, base_sum);
+  }
+  if (r == 0u && group > 0u && lane == 0u) {  // first tile of a group: publish the group's start
+    unsigned long long* p = &a.start1[2 * (size_t)group];
+    __hip_atomic_store(p, ((unsigned long long)a.epoch << 32) | base_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, ((unsigned long long)a.epoch << 32) | base_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -586,7 +682,7 @@ struct CensusArgs {
                   // [1] += number of instances whose mesh id is outside the table (the frame kernel gathers
                   //         meshes[mesh_id] unchecked: such an upload is refused, as mip_set_instances refuses it on the host)
 };
-// (static: this header is included by two translation units, mip_api.hip and stages_tu.hip)
+// (static: this header is included by every translation unit of the library; launched from api_context.hip)
 static __global__ __launch_bounds__(256) __attribute__((unused)) void mip_count_nonfinite_kernel(const CensusArgs a) {
   uint32_t bad = 0, bad_id = 0;
   for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.count; k += gridDim.x * 256u) {
@@ -639,14 +735,120 @@ __device__ __forceinline__ void wire_packed_copy_out(uint32_t* body, const uint3
   }
 }
 
+// Model matrix + world box of one instance in the arithmetic tier its WAVE takes (kGeneral) or the separable fold
+// (census-selected launches). Shared by the owner of a tile and by a wave that computes the tile's aggregate in its
+// place (help_tile_aggregate): same loads, same functions, same tier decision per 64 consecutive instances.
+template <bool kBoxOverride, bool kGeneral, class Args>
+__device__ __forceinline__ void instance_tiered(const Args& a, uint32_t il, const float (&r)[3][3], float px, float py, float pz,
+                                                float sc, MeshEntry& mb, Instance& inst) {
+  if constexpr (kGeneral) {
+    float mag = finite_magnitude(r, px, py, pz, sc);
+    if constexpr (kBoxOverride) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
+      const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;  // {min xyz, -}, {max xyz, -}
+      const float4 lo = b4[0], hi = b4[1];
+      mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
+      mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
+    }
+    // the instance's own box: a mesh-table box is finite, a box override may be anything
+    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
+    mag += box_abs;
+    const bool all_finite = mag < kFiniteLimit;
+    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
+    // three tiers, chosen per wave: the separable fold; the corner enumeration (finite inputs whose
+    // intermediate values may overflow); the literal chain (non-finite inputs)
+    if (__builtin_expect(__any(!separable), 0)) {
+      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
+      else instance_fast(r, px, py, pz, sc, mb, inst);
+    } else {
+      instance_separable(r, px, py, pz, sc, mb, inst);
+    }
+  } else {
+    instance_separable(r, px, py, pz, sc, mb, inst);  // the upload-time census found every instance separable_safe
+  }
+}
+
+// pick_lod (helpers.rs:3-11) against the frame's reference point, as the frame kernel evaluates it.
+__device__ __forceinline__ bool lod_is_far(const float (&cam)[3], float px, float py, float pz) {
+  const float dx = cam[0] - px, dy = cam[1] - py, dz = cam[2] - pz;
+  const float dist_sq = dx * dx + dy * dy + dz * dz;
+  return dist_sq > kLodDistSqThreshold;
+}
+
+// The kernel's argument block as the COLD path sees it: re-read from the kernarg segment through a pointer the compiler
+// cannot see through. A cold path that used the hot path's copies (the six planes, the camera, eight base pointers: ~45
+// scalar registers) would keep them alive across the whole kernel: measured, the allocator then parks them in vector-
+// register lanes — ~50 v_writelane / s_mov at the head of every workgroup, 1 M instances 18.65 -> 19.3 us. Reloading
+// costs the hot path nothing.
+template <class Args>
+__device__ __forceinline__ const __attribute__((address_space(4))) Args* cold_kernel_args() {
+  typedef const __attribute__((address_space(4))) Args* Ptr;
+  Ptr p = (Ptr)__builtin_amdgcn_kernarg_segment_ptr();  // the kernels here take ONE argument, by value: it starts the segment
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// The frame of a launch (planes, LOD reference point) for the cold path: from the frame ring of a recorded launch, or
+// from the argument block.
+__device__ __forceinline__ void cold_frame(const __attribute__((address_space(4))) KernelArgs* ka, float (&planes)[24], float (&cam)[3]) {
+  const uint32_t* ring = ka->frame_ring;
+  if (ring) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) planes[k] = __uint_as_float(__builtin_amdgcn_readfirstlane((int)ring[k]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam[k] = __uint_as_float(__builtin_amdgcn_readfirstlane((int)ring[24 + k]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) planes[k] = ka->planes[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam[k] = ka->cam[k];
+  }
+}
+
+// The aggregate {Σ index_len of the visible : 32 | emitted commands : 32} of tile u, computed by ONE wave from the
+// tile's inputs — what the tile's own four waves publish. Cold: only a wave whose predecessor has not published
+// within kPatientPolls gets here (resolve_prefix).
+template <bool kBoxOverride, bool kGeneral>
+__device__ __forceinline__ unsigned long long help_tile_aggregate(uint32_t u, uint32_t lane) {
+  const auto* ka = cold_kernel_args<KernelArgs>();
+  float planes[24], cam[3];
+  cold_frame(ka, planes, cam);
+  const float* pos = ka->pos;
+  const float4* rot = ka->rot;
+  const float* scale = ka->scale;
+  const uint32_t* mesh_id = ka->mesh_id;
+  const MeshEntry* meshes = ka->meshes;
+  const uint32_t n = ka->n;
+  struct { const float* box_override; } box_args = {ka->box_override};
+  uint32_t cnt = 0, sum = 0;
+#pragma nounroll
+  for (uint32_t w = 0; w < kWaves; ++w) {
+    const uint32_t j = u * kTile + w * 64u + lane;
+    const bool active = j < n;
+    const uint32_t jl = active ? j : n - 1u;
+    const float px = pos[3 * (size_t)jl + 0], py = pos[3 * (size_t)jl + 1], pz = pos[3 * (size_t)jl + 2];
+    const float4 q = rot[jl];
+    const float sc = scale[jl];
+    const uint32_t mesh = mesh_id[jl];
+    const float4 mb0 = *reinterpret_cast<const float4*>(&meshes[mesh].min_x);
+    const float4 mb1 = *reinterpret_cast<const float4*>(&meshes[mesh].max_x);
+    MeshEntry mb;
+    mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
+    mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
+    float r[3][3];
+    quat_to_rotation(q.x, q.y, q.z, q.w, r);
+    Instance inst;
+    instance_tiered<kBoxOverride, kGeneral>(box_args, jl, r, px, py, pz, sc, mb, inst);
+    const bool visible = active && !coarse_culled(inst, planes);
+    const uint32_t len = lod_is_far(cam, px, py, pz) ? mb.len1 : mb.len0;
+    cnt += (uint32_t)__popcll(__ballot(visible && len > 0u));
+    sum += wave_sum(visible ? len : 0u);
+  }
+  return ((unsigned long long)sum << 32) | cnt;
+}
+
 // Tile aggregate assembled in LDS by the four waves: {Σ index_len : 32 | arrivals : 8 | - : 8 | count : 16}.
 constexpr uint32_t kAggArrivalShift = 24;
 
-// kTicketedTiles: a workgroup's tile number comes from a ticket counter instead of blockIdx.x. Tiles
-// wait only for lower-numbered tiles, and a ticket is only ever held by a workgroup that is already
-// running, so the waits cannot deadlock whatever order the hardware starts workgroups in — at the
-// price of one atomic round trip at the head of every workgroup. The library switches to this
-// variant after a MIP_ERR_TIMEOUT (or with MIP_CFG_ORDERED_TILES); the default keeps blockIdx.x.
 // kBoxOverride: every instance brings its own mesh-space box (KernelArgs.box_override; the skinned
 // extension).
 // kGeneral: the kernel carries the literal arithmetic chain for non-finite inputs (taken per wave).
@@ -668,7 +870,7 @@ constexpr uint32_t kAggArrivalShift = 24;
 // kWire: 1 = the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above), 2 = in its
 // packed form (MIP_OUT_WIRE_PACKED, wire_packed_copy_out; KernelArgs.wire_index_bits); 0 = 20-byte commands. A template
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
-template <bool kTicketedTiles, bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0>
+template <bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0>
 __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
   static_assert(kOrder == 1 || kOrder == 3, "unknown order");
   static_assert(!kWire || !kBoxOverride, "skinned frames do not emit the wire form");
@@ -687,19 +889,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool want_cmds = a.cmds != nullptr;
   uint32_t tile = blockIdx.x;
-  if constexpr (kTicketedTiles) {
-    __shared__ uint32_t s_tile;
-    if (tid == 0) {
-      const bool no_ticket = a.tile_agg_out != nullptr;
-      s_tile = no_ticket ? blockIdx.x : atomicAdd(a.tile_ticket, 1u);
-      // the holder of the last ticket knows every other workgroup already has its own: it re-arms
-      // the counter for the next launch on this frame slot
-      if (!no_ticket && s_tile == a.n_tiles - 1u) __hip_atomic_store(a.tile_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_tile_agg = 0ull;
-    }
-    __syncthreads();
-    tile = s_tile;
-  }
+#ifdef MIP_DEBUG_STAMPS
+  if (a.debug_tile_mult) tile = (uint32_t)(((unsigned long long)blockIdx.x * a.debug_tile_mult + a.debug_tile_add) % a.n_tiles);
+#endif
   const uint32_t tile_first = tile * kTile;
   const uint32_t i = tile_first + tid;
   const bool active = i < a.n;
@@ -727,18 +919,19 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     first_index_base = a.first_index_base;
   }
 
+  // a predecessor that does not publish is not waited for: this wave computes its aggregate itself (resolve_prefix)
+  auto help = [lane](uint32_t u) { return help_tile_aggregate<kBoxOverride, kGeneral>(u, lane); };
+
   // ---- loads: 36 B per instance ----
   const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
   const float4 q = a.rot[il];
   const float sc = a.scale[il];
   const uint32_t mesh = a.mesh_id[il];
-  if constexpr (!kTicketedTiles) {
-    // the LDS word the waves add their aggregates to; the barrier does not wait for the instance
-    // loads above, and every wave of the workgroup has only just started
-    if (want_cmds) {
-      if (tid == 0) s_tile_agg = 0ull;
-      __syncthreads();
-    }
+  // the LDS word the waves add their aggregates to; the barrier does not wait for the instance
+  // loads above, and every wave of the workgroup has only just started
+  if (want_cmds) {
+    if (tid == 0) s_tile_agg = 0ull;
+    __syncthreads();
   }
   // (a copy of small mesh tables in LDS was measured: no gain — profiles/r02_lds_pad_occupancy_and_mesh_cache_ab.txt)
   const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
@@ -751,30 +944,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   float r[3][3];
   quat_to_rotation(q.x, q.y, q.z, q.w, r);
   Instance inst;
-  if constexpr (kGeneral) {
-    float mag = finite_magnitude(r, px, py, pz, sc);
-    if constexpr (kBoxOverride) {  // skinned instances: the posed mesh-space box computed by mip_skinned_bounds_kernel
-      const float4* b4 = reinterpret_cast<const float4*>(a.box_override) + 2 * (size_t)il;  // {min xyz, -}, {max xyz, -}
-      const float4 lo = b4[0], hi = b4[1];
-      mb.min_x = lo.x; mb.min_y = lo.y; mb.min_z = lo.z;
-      mb.max_x = hi.x; mb.max_y = hi.y; mb.max_z = hi.z;
-    }
-    // the instance's own box: a mesh-table box is finite, a box override may be anything
-    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
-    mag += box_abs;
-    const bool all_finite = mag < kFiniteLimit;
-    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
-    // three tiers, chosen per wave: the separable fold; the corner enumeration (finite inputs whose
-    // intermediate values may overflow); the literal chain (non-finite inputs)
-    if (__builtin_expect(__any(!separable), 0)) {
-      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
-      else instance_fast(r, px, py, pz, sc, mb, inst);
-    } else {
-      instance_separable(r, px, py, pz, sc, mb, inst);
-    }
-  } else {
-    instance_separable(r, px, py, pz, sc, mb, inst);  // the upload-time census found every instance separable_safe
-  }
+  instance_tiered<kBoxOverride, kGeneral>(a, il, r, px, py, pz, sc, mb, inst);
 
   MIP_STAMP(1);
   // The emitting lanes need their mesh's vertex_offset. Its gather used to sit behind the keep decision, i.e. one L2
@@ -789,9 +959,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // ---- frustum test, LOD, command length ----
   const bool culled = coarse_culled(inst, planes);
   const bool visible = active && !culled;
-  const float dx = cam[0] - px, dy = cam[1] - py, dz = cam[2] - pz;
-  const float dist_sq = dx * dx + dy * dy + dz * dz;
-  const bool far_lod = dist_sq > kLodDistSqThreshold;
+  const bool far_lod = lod_is_far(cam, px, py, pz);
   const uint32_t len = far_lod ? mb.len1 : mb.len0;  // len1/offset1 already fall back to LOD 0
   const bool keep = visible && len > 0u;  // compact_draw_stream.comp:41 `indexCount > 0`
   const uint32_t len_vis = visible ? len : 0u;
@@ -802,8 +970,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const uint32_t rank_in_wave = lanes_below(keep_mask);
   const uint32_t incl_sum = wave_inclusive_scan(len_vis);
 #ifdef MIP_DEBUG_STAMPS
-  // fault injection (diagnostic build only): one tile never publishes, so every later tile's
-  // bounded wait must expire and the launch must end with MIP_ERR_TIMEOUT instead of hanging
+  // fault injection (diagnostic build only): one tile never publishes, so every later tile has to compute
+  // that tile's aggregate itself (resolve_prefix) — and the launch must end with the right bytes
   const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
 #else
   const bool skip_publish = false;
@@ -819,16 +987,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     bool publish = ((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish;
     if (publish) publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
   }
-  if constexpr (kTicketedTiles) {
-    // launch 1 of a large ordered frame: no commands here, only the tile's aggregate — written by the last wave to get here
-    if (a.tile_agg_out && lane == 63u) {
-      const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | (uint32_t)__popcll(keep_mask);
-      const unsigned long long all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
-      // (adding the pair to a per-group accumulator here — 64 agent-scope atomic adds per address — cost this launch 10 us at 1 M)
-      if (((uint32_t)all >> kAggArrivalShift) == kWaves) a.tile_agg_out[tile] = make_uint2((uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
-    }
-  }
-
   // ---- stage the matrix rows for the transposed store (three conflict-free ds_write_b128, 48-B pitch) ----
   if (a.model || a.tlas_instances) {
     float4* dst = reinterpret_cast<float4*>(&s_mat[tid * 12]);
@@ -931,8 +1089,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     __syncthreads();
     MIP_STAMP(3);
     if (wave != 0) return;
+    store_aabb();  // wave 0's own (optional) boxes go out before the look-up: nothing of the instance lives across it
     uint32_t base_count = 0, base_sum = 0;
-    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help);
     if (lane == 0 && tile == a.n_tiles - 1u) {
       *a.draw_count = base_count + tile_count;
       if (a.index_total) *a.index_total = base_sum + tile_sum;
@@ -942,7 +1101,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     if constexpr (kWire) {
       if constexpr (kWire == 2) wire_packed_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count, first_instance_base, a.wire_index_bits);
       else wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
-      store_aabb();
       MIP_STAMP(5);
       return;
     }
@@ -956,7 +1114,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     if (a.src_index_offset)
       for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
-    store_aabb();
     MIP_STAMP(5);
     return;
   }
@@ -1009,9 +1166,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   }
 
   // ---- exclusive prefix over the earlier tiles ----
+  store_aabb();  // (optional output) before the look-up: nothing of the instance lives across it
   uint32_t base_count = 0, base_sum = 0;
 #ifndef MIP_EXP_NO_HOP  // tuning builds only: what the kernel costs without the cross-tile look-up (results are wrong)
-  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum);
+  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help);
 #else
   base_count = tile * 64u;
 #ifdef MIP_EXP_FAKE_DELAY  // idle for the time a look-up takes, without its memory traffic
@@ -1032,7 +1190,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   if constexpr (kWire) {
     if constexpr (kWire == 2) wire_packed_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count, first_instance_base, a.wire_index_bits);
     else wire_copy_out(a.cmds, s_cmd, lane, base_count, first_index_add, tile_count);
-    store_aabb();
     MIP_STAMP(5);
     return;
   }
@@ -1046,85 +1203,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   }
   if (a.src_index_offset)
     for (uint32_t k = lane; k < tile_count; k += 64u) a.src_index_offset[base_count + k] = s_cmd[k * kCmdLdsWords + 5u];
-  store_aabb();
   MIP_STAMP(5);
-}
-
-// ---------------------------------------------------------------------------------------
-// ordered tiles, large launches: the prefix without any wait (three launches)
-// ---------------------------------------------------------------------------------------
-// MIP_CFG_ORDERED_TILES (or a context that has had a stalled frame) must not depend on the order workgroups start in.
-// Tickets give that at ~11 ns per tile, serialised on one address: fine for small launches, 55 us at 1 M instances
-// against 18. From a few hundred thousand instances on the library instead runs THREE launches none of which ever
-// waits for another workgroup:
-//   1  the frame kernel without commands (its ticketed instantiation with KernelArgs.tile_agg_out set: tile = blockIdx.x, no
-//      ticket, no publish, no look-up): matrices, boxes, TLAS rows, the visibility bitmap; per tile the pair {emitted commands,
-//      sum of index_len};
-//   2  mip_tile_scan_kernel (below): one workgroup sums the pairs of every group of kTileGroup consecutive tiles (one coalesced
-//      load and a wave reduction per group), one scan across the workgroup gives the exclusive group prefixes and the totals
-//      (draw_count, index total) — 611 groups at 10 M instances;
-//   3  mip_emit_commands_kernel (emit_kernel.hpp): the commands, from the bitmap, the group prefix and the pairs of the earlier
-//      tiles of the own group.
-// (Round 3's first version ran an aggregate-only launch, a scan over all tiles and then the whole frame kernel with the prefix
-// given: 30.2 us at 1 M, 277 us at 10 M against this one's figures in profiles/r03_ordered_tiles_three_pass.txt.)
-struct TileScanArgs {
-  const uint2* tile_agg;   // n_tiles pairs {count, sum index_len} (launch 1)
-  uint2* group_prefix;     // exclusive prefix per group of kTileGroup tiles, out
-  uint32_t n_tiles;
-  uint32_t* draw_count;
-  uint32_t* index_total;  // or null
-};
-
-// (static: this header is included by two translation units)
-// One workgroup of 16 waves. A group is kTileGroup = 64 consecutive tiles = what one wave loads in one coalesced instruction:
-// wave w takes groups w, w + 16, ... (independent loads, no barrier), reduces each across its lanes and leaves the sum in LDS;
-// after one barrier the up to 1 024 group sums are scanned across the workgroup. More than 65 536 tiles (16.7 M instances):
-// the outer loop runs again with the running totals.
-static __global__ __launch_bounds__(1024) __attribute__((unused)) void mip_tile_scan_kernel(const TileScanArgs a) {
-  __shared__ uint32_t s_gc[1024], s_gs[1024];
-  __shared__ uint32_t s_c[16], s_s[16];
-  __shared__ uint32_t s_run_c, s_run_s;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t n_groups = (a.n_tiles + kTileGroup - 1u) / kTileGroup;
-  if (tid == 0u) { s_run_c = 0u; s_run_s = 0u; }
-  for (uint32_t base = 0; base < n_groups; base += 1024u) {
-    const uint32_t here = n_groups - base < 1024u ? n_groups - base : 1024u;
-    for (uint32_t g0 = wave; g0 < here; g0 += 64u) {  // four groups per step: their loads are in flight together
-      uint2 v[4];
-#pragma unroll
-      for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t g = g0 + 16u * k;
-        const uint32_t t = (base + g) * kTileGroup + lane;
-        v[k] = (g < here && t < a.n_tiles) ? a.tile_agg[t] : make_uint2(0u, 0u);
-      }
-#pragma unroll
-      for (uint32_t k = 0; k < 4u; ++k) {
-        const uint32_t g = g0 + 16u * k;
-        const uint32_t c = wave_sum(v[k].x), s = wave_sum(v[k].y);
-        if (lane == 0u && g < here) { s_gc[g] = c; s_gs[g] = s; }
-      }
-    }
-    __syncthreads();
-    const uint32_t vc = tid < here ? s_gc[tid] : 0u, vs = tid < here ? s_gs[tid] : 0u;
-    const uint32_t ic = wave_inclusive_scan(vc), is = wave_inclusive_scan(vs);
-    if (lane == 63u) { s_c[wave] = ic; s_s[wave] = is; }
-    __syncthreads();
-    uint32_t bc = s_run_c, bs = s_run_s, tc = 0, ts = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) {
-      if (w < wave) { bc += s_c[w]; bs += s_s[w]; }
-      tc += s_c[w];
-      ts += s_s[w];
-    }
-    if (tid < here) a.group_prefix[base + tid] = make_uint2(bc + ic - vc, bs + is - vs);
-    __syncthreads();
-    if (tid == 0u) { s_run_c += tc; s_run_s += ts; }
-    __syncthreads();
-  }
-  if (tid == 0u) {
-    *a.draw_count = s_run_c;
-    if (a.index_total) *a.index_total = s_run_s;
-  }
 }
 
 }  // namespace mip

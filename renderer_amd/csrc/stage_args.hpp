@@ -8,7 +8,7 @@
 // the moves are pure cost. Measured per kernel (profiles/r03_triangle_no_slp_ab.txt, r03_no_slp_by_kernel.txt): per-
 // triangle stage -7 %, skinning -11 .. -16 %, four views -6 %, light lists x16 -4 %, frame kernel 100 k .. 800 k
 // -2 .. -4 %; the stores-first frame kernel of large launches (the headline) is the one kernel that is not faster
-// that way and stays in mip_api.hip, which sees only this header.
+// that way and stays in api_frame.hip, which sees only this header.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -61,6 +61,9 @@ struct TrianglePartsArgs {
   TriangleArgs t;
   unsigned long long* part_status;  // [commands][kTriParts] granules {epoch : 32 | survivors : 32}
   uint32_t epoch;                   // unique per launch on this frame slot, never 0
+#ifdef MIP_DEBUG_STAMPS
+  uint32_t debug_reverse;           // diagnostic build only: work items are taken from the LAST one down (later parts first)
+#endif
 };
 
 // Launchers (defined in stages_tu.hip). Each enqueues one kernel on `stream`; errors surface through hipGetLastError.
@@ -153,36 +156,17 @@ struct ViewsArgs {
   uint32_t n_tiles;
   uint32_t bitmap_words;
   uint32_t n_views;
+#ifdef MIP_DEBUG_STAMPS
+  uint32_t debug_tile_mult, debug_tile_add;  // diagnostic build only: tile = (blockIdx.x * mult + add) % n_tiles (KernelArgs has the same)
+#endif
   ViewArgs view[kMaxViews];
 };
 
 void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const ViewsArgs& a);
 
 // ---- rows a-1 .. a-7, commands-first order (kOrder == 3 of instance_kernel.hpp: launches below ~0.9 M instances) ----
-// The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in mip_api.hip.
+// The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in api_frame.hip.
 using FrameKernelFn = void (*)(const KernelArgs);
-FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */);
-// last of the three wait-free launches of a large ordered-tiles frame (emit_kernel.hpp): the command list from the bitmap
-struct EmitArgs {
-  const float* pos;
-  const uint32_t* mesh_id;
-  const MeshEntry* meshes;
-  const MeshDraw* mesh_draw;
-  const uint32_t* bitmap;          // visibility of the frame, written by launch 1
-  const uint2* tile_agg;           // {count, sum index_len} per tile, written by launch 1
-  const uint2* group_prefix;       // exclusive {count, sum index_len} per group of kTileGroup tiles, written by launch 2; null: there
-                                   // was no launch 2 (small launches), the kernel sums the earlier tiles' pairs itself and writes
-  uint32_t* draw_count;            // ... the totals (last tile); unused otherwise
-  uint32_t* index_total;           // or null
-  uint32_t n_tiles;
-  uint32_t* cmds;                  // n*5 words, or a wire body
-  uint32_t* src_index_offset;      // or null (per-triangle stage)
-  uint32_t n;
-  uint32_t first_instance_base;
-  uint32_t first_index_base;
-  uint32_t wire_index_bits;
-  float cam[3];
-};
-void launch_emit_commands(int wire /* 0 | 1 | 2 */, uint32_t tiles, hipStream_t stream, const EmitArgs& a);
+FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */);
 
 }  // namespace mip

@@ -5,7 +5,6 @@
 #include "light_lists_kernel.hpp"
 #include "skinning_kernel.hpp"
 #include "views_kernel.hpp"
-#include "emit_kernel.hpp"
 
 namespace mip {
 
@@ -47,27 +46,20 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
   else hipLaunchKernelGGL(mip_cull_views_kernel<false>, dim3(tiles), dim3(kTile), 0, stream, a);
 }
 
-// Every kOrder == 3 instantiation of the frame kernel lives here and only here (mip_api.hip instantiates kOrder == 1):
+// Every kOrder == 3 instantiation of the frame kernel lives here and only here (api_frame.hip instantiates kOrder == 1):
 // an instantiation referenced from both units would be registered twice under one host stub.
 namespace {
 template <bool kBox, bool kGeneral, int kWire>
-FrameKernelFn commands_first(bool ticketed) {
-  return ticketed ? (FrameKernelFn)mip_instance_pipeline_kernel<true, kBox, kGeneral, 3, kWire>
-                  : (FrameKernelFn)mip_instance_pipeline_kernel<false, kBox, kGeneral, 3, kWire>;
+FrameKernelFn commands_first() {
+  return (FrameKernelFn)mip_instance_pipeline_kernel<kBox, kGeneral, 3, kWire>;
 }
 }  // namespace
 
-FrameKernelFn frame_kernel_commands_first(bool ticketed, bool box_override, bool general, int wire) {
-  if (box_override) return commands_first<true, true, 0>(ticketed);  // skinned frames: always general, never wire
-  if (wire == 2) return general ? commands_first<false, true, 2>(ticketed) : commands_first<false, false, 2>(ticketed);
-  if (wire == 1) return general ? commands_first<false, true, 1>(ticketed) : commands_first<false, false, 1>(ticketed);
-  return general ? commands_first<false, true, 0>(ticketed) : commands_first<false, false, 0>(ticketed);
-}
-
-void launch_emit_commands(int wire, uint32_t tiles, hipStream_t stream, const EmitArgs& a) {
-  if (wire == 2) hipLaunchKernelGGL(mip_emit_commands_kernel<2>, dim3(tiles), dim3(kTile), 0, stream, a);
-  else if (wire == 1) hipLaunchKernelGGL(mip_emit_commands_kernel<1>, dim3(tiles), dim3(kTile), 0, stream, a);
-  else hipLaunchKernelGGL(mip_emit_commands_kernel<0>, dim3(tiles), dim3(kTile), 0, stream, a);
+FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire) {
+  if (box_override) return commands_first<true, true, 0>();  // skinned frames: always general, never wire
+  if (wire == 2) return general ? commands_first<false, true, 2>() : commands_first<false, false, 2>();
+  if (wire == 1) return general ? commands_first<false, true, 1>() : commands_first<false, false, 1>();
+  return general ? commands_first<false, true, 0>() : commands_first<false, false, 0>();
 }
 
 }  // namespace mip

@@ -446,12 +446,16 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
   for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
   const uint32_t items = count * kTriParts;
 
-  // Items are dealt by a static stride over a grid that is resident as a whole (the host launches at most what fits
-  // the chip at this kernel's register budget): a part's predecessors belong to workgroups that are running, so the
-  // waits below end — and they are bounded anyway. (A ticket counter was measured first: one returning atomic per
-  // item on one address serialises at ~11 ns each, 82 against 48 us at 1 000 instances.)
-  for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+  // Items are dealt by a static stride over a grid the host sizes to be resident as a whole, so a part's predecessors
+  // normally belong to workgroups that are running and have published by the time they are looked at; nothing depends on
+  // that: a part that has not published is counted by the wave that needs it (below). (A ticket counter was measured
+  // first: one returning atomic per item on one address serialises at ~11 ns each, 82 against 48 us at 1 000 instances.)
+  for (uint32_t dealt = blockIdx.x; dealt < items; dealt += gridDim.x) {
     __syncthreads();  // s_counts / s_prefix of the previous item have been read
+    uint32_t item = dealt;
+#ifdef MIP_DEBUG_STAMPS
+    if (pa.debug_reverse) item = items - 1u - dealt;
+#endif
     const uint32_t c = item / kTriParts, part = item % kTriParts;
 
     const uint32_t index_count = a.cmds[c * kCmdWords + 0];
@@ -524,19 +528,47 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
       const bool need = lane < part;
       bool ready = !need;
       uint32_t got = 0, polls = 0;
-      const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-      bool ok = true;
       for (;;) {
         if (!ready) {
           const unsigned long long g = status_load(&status[lane]);
           if ((uint32_t)(g >> 32) == pa.epoch) { ready = true; got = (uint32_t)g; }
         }
         if (__all(ready)) break;
-        if (++polls > kSpinMinPolls && __builtin_amdgcn_s_memrealtime() - t_start > kSpinTimeoutTicks) { ok = false; break; }
+        if (__builtin_expect(++polls > kPatientPolls, 0)) break;
         __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok && lane == 0) raise_error(a.error_flag, kErrPartsTimeout);
-      prefix = ok ? wave_sum(got) : 0u;
+      // An earlier part that has not published within the patient polls is not waited for (its workgroup may not be
+      // running: instance_kernel.hpp, "no wait depends on another workgroup ever running"): this wave counts that part's
+      // survivors itself — the same triangles through the same test, 64 per step — and publishes the count for it.
+      unsigned long long missing = __ballot(!ready);
+      while (__builtin_expect(missing != 0ull, 0)) {  // wave-uniform
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(missing));
+        unsigned long long g = status_load(&status[p]);
+        if ((uint32_t)(g >> 32) != pa.epoch) {
+          const uint32_t b = p * per_part < n_tris ? p * per_part : n_tris;
+          const uint32_t e = b + per_part < n_tris ? b + per_part : n_tris;
+          uint32_t survivors = 0;
+          for (uint32_t t0 = b; t0 < e; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            const bool valid = t < e;
+            uint32_t j0 = 0, j1 = 0, j2 = 0;
+            if (valid) {
+              const uint32_t* ip = tri_indices + (size_t)t * 3;
+              j0 = ip[0]; j1 = ip[1]; j2 = ip[2];
+            }
+            const bool keep = valid && !triangle_culled(affine, model, pv, a.vertices, (long long)vertex_offset, j0, j1, j2);
+            survivors += (uint32_t)__popcll(__ballot(keep));
+          }
+          g = ((unsigned long long)pa.epoch << 32) | survivors;
+          if (lane == 0u) {
+            __hip_atomic_store(&status[p], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(a.error_flag + kHelpCounterWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        if (lane == p) got = (uint32_t)g;
+        missing &= ~(1ull << p);
+      }
+      prefix = wave_sum(got);
       if (lane == 0) s_prefix = prefix;
     }
     __syncthreads();

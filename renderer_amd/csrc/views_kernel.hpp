@@ -39,6 +39,56 @@ __device__ __forceinline__ bool view_culled(const float (&h)[3], const float (&c
   return outside;
 }
 
+// The aggregate {Σ index_len of the visible : 32 | emitted commands : 32} of tile u FOR ONE VIEW, computed by one wave from
+// the tile's inputs: what resolve_prefix falls back to when a predecessor has not published (instance_kernel.hpp).
+template <bool kGeneral>
+__device__ __forceinline__ unsigned long long help_view_aggregate(uint32_t v, uint32_t u, uint32_t lane) {
+  const auto* ka = cold_kernel_args<ViewsArgs>();  // re-read from the kernarg segment: nothing of the hot path is kept alive for this
+  float planes[24], cam[3];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) planes[k] = ka->view[v].planes[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cam[k] = ka->view[v].cam[k];
+  const float* pos = ka->pos;
+  const float4* rot = ka->rot;
+  const float* scale = ka->scale;
+  const uint32_t* mesh_id = ka->mesh_id;
+  const MeshEntry* meshes = ka->meshes;
+  const uint32_t n = ka->n;
+  struct { const float* box_override; } no_box = {nullptr};
+  uint32_t cnt = 0, sum = 0;
+#pragma nounroll
+  for (uint32_t w = 0; w < kWaves; ++w) {
+    const uint32_t j = u * kTile + w * 64u + lane;
+    const bool active = j < n;
+    const uint32_t jl = active ? j : n - 1u;
+    const float px = pos[3 * (size_t)jl + 0], py = pos[3 * (size_t)jl + 1], pz = pos[3 * (size_t)jl + 2];
+    const float4 q = rot[jl];
+    const float sc = scale[jl];
+    const uint32_t mesh = mesh_id[jl];
+    const float4 mb0 = *reinterpret_cast<const float4*>(&meshes[mesh].min_x);
+    const float4 mb1 = *reinterpret_cast<const float4*>(&meshes[mesh].max_x);
+    MeshEntry mb;
+    mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
+    mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
+    float r[3][3];
+    quat_to_rotation(q.x, q.y, q.z, q.w, r);
+    Instance inst;
+    instance_tiered<false, kGeneral>(no_box, jl, r, px, py, pz, sc, mb, inst);
+    float box_h[3], box_c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      box_h[k] = (inst.maxs[k] - inst.mins[k]) * 0.5f;
+      box_c[k] = (inst.mins[k] + inst.maxs[k]) * 0.5f;
+    }
+    const bool visible = active && !view_culled(box_h, box_c, planes);
+    const uint32_t len = lod_is_far(cam, px, py, pz) ? mb.len1 : mb.len0;
+    cnt += (uint32_t)__popcll(__ballot(visible && len > 0u));
+    sum += wave_sum(visible ? len : 0u);
+  }
+  return ((unsigned long long)sum << 32) | cnt;
+}
+
 // kGeneral = false: the upload-time census found every instance finite and separable-safe (as for the frame kernel).
 template <bool kGeneral>
 __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArgs a) {
@@ -47,7 +97,10 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   static_assert(kWaves >= kMaxViews, "one wave per view finishes that view");
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t tile = blockIdx.x;
+  uint32_t tile = blockIdx.x;
+#ifdef MIP_DEBUG_STAMPS
+  if (a.debug_tile_mult) tile = (uint32_t)(((unsigned long long)blockIdx.x * a.debug_tile_mult + a.debug_tile_add) % a.n_tiles);
+#endif
   const uint32_t tile_first = tile * kTile;
   const uint32_t i = tile_first + tid;
   const bool active = i < a.n;
@@ -67,21 +120,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   float r[3][3];
   quat_to_rotation(q.x, q.y, q.z, q.w, r);
   Instance inst;
-  if constexpr (kGeneral) {
-    // the three arithmetic tiers of the instance kernel, chosen per wave (instance_kernel.hpp)
-    const float mag = finite_magnitude(r, px, py, pz, sc);
-    const float box_abs = fabsf(mb.min_x) + fabsf(mb.min_y) + fabsf(mb.min_z) + fabsf(mb.max_x) + fabsf(mb.max_y) + fabsf(mb.max_z);
-    const bool all_finite = mag < kFiniteLimit;
-    const bool separable = all_finite && separable_bound(r, px, py, pz, sc, box_abs) < kSeparableLimit;
-    if (__builtin_expect(__any(!separable), 0)) {
-      if (__any(!all_finite)) instance_general(r, px, py, pz, sc, mb, inst);
-      else instance_fast(r, px, py, pz, sc, mb, inst);
-    } else {
-      instance_separable(r, px, py, pz, sc, mb, inst);
-    }
-  } else {
-    instance_separable(r, px, py, pz, sc, mb, inst);
-  }
+  instance_tiered<false, kGeneral>(a, il, r, px, py, pz, sc, mb, inst);  // the arithmetic tiers of the instance kernel
   float box_h[3], box_c[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -159,7 +198,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
 #pragma unroll
       for (uint32_t w = 0; w < kWaves; ++w) { tile_count += s_wave_count[my_view][w]; tile_sum += s_wave_sum[my_view][w]; }
       uint32_t base_count = 0, base_sum = 0;
-      if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum);
+      if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum, [my_view, lane](uint32_t u) { return help_view_aggregate<kGeneral>(my_view, u, lane); });
       if (lane == 0) {
         if (tile == a.n_tiles - 1u) {
           *view.draw_count = base_count + tile_count;
@@ -195,7 +234,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
 #pragma unroll
   for (uint32_t w = 0; w < kWaves; ++w) { tile_count += s_wave_count[my_view][w]; tile_sum += s_wave_sum[my_view][w]; }
   uint32_t base_count = 0, base_sum = 0;
-  if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum);
+  if (tile > 0) resolve_prefix(view, tile, lane, base_count, base_sum, [my_view, lane](uint32_t u) { return help_view_aggregate<kGeneral>(my_view, u, lane); });
   if (lane == 0 && tile == a.n_tiles - 1u) {
     *view.draw_count = base_count + tile_count;
     if (view.index_total) *view.index_total = base_sum + tile_sum;

@@ -1,4 +1,4 @@
-// spin_rccl.hip — TEST DOUBLE for the RCCL entry points the library resolves at run time (mip_api.hip, rccl()),
+// spin_rccl.hip — TEST DOUBLE for the RCCL entry points the library resolves at run time (api_sharded.hip, rccl()),
 // like fake_rccl.cpp, but shaped like the real thing where it matters for the kernels that run BESIDE it:
 //
 //   * ncclAllGather returns at once; the exchange is a KERNEL enqueued on the caller's stream (stream-ordered,

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mip_abi_version() == 3
+    assert lib.mip_abi_version() == 4
     # a pure function of the ABI (no device): the bits a packed wire record leaves for the instance index — the library's
     # answer, the Python mirror's and the header's wording (31 - ceil(log2(n_meshes))) agree
     from renderer_amd.pipeline import wire_index_bits

@@ -395,10 +395,10 @@ def test_plain_c_host(ra):
     assert 0 < int(fields["commands"]) == int(fields["visible"]) < 1000
 
 
-def test_ordered_tiles_variant(ra, oracle_mod):
-    """MIP_CFG_ORDERED_TILES: tile numbers come from a counter (no assumption about the order workgroups
-    start in). Same results, for the plain frame, frames in flight, recorded launch graphs and a skinned
-    frame; the counter re-arms itself between launches."""
+def test_ordered_tiles_flag_is_accepted_and_changes_nothing(ra, oracle_mod):
+    """MIP_CFG_ORDERED_TILES (ABI <= 3: tile numbers from a counter / three wait-free launches) is accepted and ignored
+    since ABI 4 — every launch is independent of dispatch order. Same results, for the plain frame, frames in flight,
+    recorded launch graphs and a skinned frame."""
     import torch
 
     from renderer_amd.pipeline import make_frame
@@ -412,7 +412,7 @@ def test_ordered_tiles_variant(ra, oracle_mod):
             p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
             for rep in range(3):
                 assert_parity(p.run_host(s["planes"], s["cam_pos"]), want, f"ordered n={n} rep={rep}")
-    s = ra.scene.make_scene(3, n=40_000)  # 157 tiles: still the ticketed kernel (larger ordered launches are not recorded as graphs)
+    s = ra.scene.make_scene(3, n=40_000)
     want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
     with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2, ordered_tiles=True) as p:
         p.set_mesh_table(s["meshes"])
@@ -448,112 +448,166 @@ def test_ordered_tiles_variant(ra, oracle_mod):
         assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
 
 
-def test_bounded_wait_ends_a_stuck_launch_with_an_error():
-    """Fault injection (diagnostic build): tile 5 never publishes its aggregate. Every later tile
-    depends on it; the bounded in-kernel wait must expire (0.5 s), the launch must finish, and the
-    ABI must report MIP_ERR_TIMEOUT instead of hanging the GPU. The context stays usable."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
-    code = r'''
-import os, sys, time
-sys.path.insert(0, sys.argv[1])
+_ORDER_CHILD = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
-os.environ["MIP_DEBUG_SKIP_PUBLISH_TILE"] = "5"
-import renderer_amd
-from renderer_amd import scene
-s = scene.make_scene(3, n=8192)
-p = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]))
-p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-t0 = time.time()
-try:
-    p.run_host(s["planes"], s["cam_pos"])
-    print("NOERROR")
-except renderer_amd.MipError as e:
-    print("CODE", e.code, "%.2f" % (time.time() - t0))
-del os.environ["MIP_DEBUG_SKIP_PUBLISH_TILE"]
-r = p.run_host(s["planes"], s["cam_pos"])   # the same context recovers on the next frame (now with ordered tiles)
-print("RECOVERED", r["draw_count"])
-q = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]))
-q.set_mesh_table(s["meshes"]); q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-r2 = q.run_host(s["planes"], s["cam_pos"])
-print("SAME", int(r["draw_cmds"].tobytes() == r2["draw_cmds"].tobytes() and (r["visible_bitmap"] == r2["visible_bitmap"]).all()))
-'''
-    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    lines = out.stdout.split("\n")
-    code_line = [l for l in lines if l.startswith("CODE")]
-    assert code_line and code_line[0].split()[1] == "-7", out.stdout  # MIP_ERR_TIMEOUT
-    assert float(code_line[0].split()[2]) < 10.0
-    assert any(l.startswith("RECOVERED") and int(l.split()[1]) > 0 for l in lines), out.stdout
-    assert "SAME 1" in lines, out.stdout
-
-
-def test_a_timed_out_frame_is_issued_again_by_the_library():
-    """Fault injection (diagnostic build), one-shot: tile 5 of the FIRST launch(es) never publishes. The frame's bounded wait expires;
-    the library switches to ordered tiles and issues the frame(s) on record again itself: the caller sees MIP_OK and the right
-    outputs (MipTimings.timeout_recoveries counts it) — synchronously (host outputs), and at mip_wait for async frames on two frame
-    slots. With more than one frame per slot in flight the error is reported as before."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
-    code = r'''
-import os, sys, time
-sys.path.insert(0, sys.argv[1])
-mode = sys.argv[2]
-os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
-os.environ["MIP_DEBUG_SKIP_PUBLISH_ONCE"] = "5"
-os.environ["MIP_DEBUG_SKIP_PUBLISH_LAUNCHES"] = {"sync": "1", "async2": "2", "deep": "1"}[mode]
+what = sys.argv[2]
 import numpy as np, torch
-import renderer_amd
+import oracle, renderer_amd
 from renderer_amd import scene
 from renderer_amd.pipeline import make_frame
-s = scene.make_scene(3, n=8192)
-q = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]), ordered_tiles=True)   # the reference result: never stalls
-q.set_mesh_table(s["meshes"]); q.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-p = renderer_amd.InstancePipeline(s["n"], len(s["meshes"]), frames_in_flight=1 if mode == "sync" else 2)
-p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-t0 = time.time()
-if mode == "sync":
-    r = p.run_host(s["planes"], s["cam_pos"])          # the stuck launch happens in here
-    want = q.run_host(s["planes"], s["cam_pos"])       # (the one-shot injection has been used up)
-    ok = r["draw_cmds"].tobytes() == want["draw_cmds"].tobytes() and (r["visible_bitmap"] == want["visible_bitmap"]).all() and r["draw_count"] > 0
-    print("SYNC", int(ok), p.timings()["timeout_recoveries"], "%.2f" % (time.time() - t0))
-else:
-    dev = torch.device("cuda", 0)
+from cpu_pipeline import decode_wire, unpack_wire
+dev = torch.device("cuda", 0)
+
+def frame_case(n, order, wire=False, nonfinite=False):
+    os.environ["MIP_TUNE_ORDER"] = order
+    s = scene.make_scene(3, n=n)
+    if nonfinite:
+        s["pos"][7] = np.nan; s["scale"][300] = np.inf; s["rot"][n - 3] = [3e38, 3e38, 0, 0]
+    want = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=8,
+                      want=("draw_cmds", "visible_bitmap"))
+    with renderer_amd.InstancePipeline(max_instances=n, max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        cmds = torch.zeros((n + 1024, 5), dtype=torch.int32, device=dev)
+        bitmap = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=dev)
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            p.run_device(make_frame(s["planes"], s["cam_pos"]), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire=wire)
+            count = int(scal[0].item())
+            assert count == want["draw_count"] and int(scal[1].item()) == want["draw_index_total"], (n, order, wire, rep, count)
+            words = cmds.cpu().numpy().view(np.uint32).reshape(-1)
+            if wire == "packed":
+                got = decode_wire(unpack_wire(words, count), count, s["meshes"])
+            elif wire:
+                got = decode_wire(words, count, s["meshes"])
+            else:
+                got = words[:count * 5]
+            assert got.tobytes() == want["draw_cmds"].tobytes(), (n, order, wire, rep)
+            assert np.array_equal(bitmap.cpu().numpy().view(np.uint32), want["visible_bitmap"]), (n, order, wire, rep)
+        return p.timings()["prefix_helps"]
+
+helps = []
+if what == "frames":
+    # 32 tiles: resident as a whole; 3 907 tiles: not (a stores-first workgroup shrinks to one wave while it looks up its
+    # prefix, so ~2 800 of those fit the chip at once: 600 k instances would still all become resident)
+    for n in (8192, 1_000_000):
+        for order in ("1", "3"):
+            helps.append(frame_case(n, order))
+    helps.append(frame_case(1_000_000, "1", wire=True))
+    helps.append(frame_case(1_000_000, "3", wire="packed"))
+    helps.append(frame_case(1_000_000, "1", nonfinite=True))   # the kernel with the fall-back arithmetic tiers helps with them
+elif what == "graphs":                 # recorded launches: the cold path reads its frame from the ring, like the hot path
+    s = scene.make_scene(3, n=1_000_000)
     cams = [np.array(c, np.float32) for c in ((0, 1, 2), (5, 1, 2))]
-    bufs = [(torch.zeros((s["n"], 5), dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32, device=dev)) for _ in cams]
-    torch.cuda.synchronize()
-    frames = 2 if mode == "async2" else 4
-    try:
-        for k in range(frames):
-            cmds, scal = bufs[k % 2]
-            p.run_device(make_frame(s["planes"], cams[k % 2]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, async_=True)
+    wants = [oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], c, threads=8, want=("draw_cmds",)) for c in cams]
+    os.environ["MIP_TUNE_GRAPH_ROUND"] = "4"   # (read when the context is created) a round = 4 frames: 2 per frame slot
+    with renderer_amd.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in cams:
+            cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev); scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        p.run_many([make_frame(s["planes"], c) for c in cams], [x[2] for x in sets], 4)
         p.wait()
-        ok = True
-        for k in range(2):
-            want = q.run_host(s["planes"], cams[k])
-            c = int(bufs[k][1][0].item())
-            ok = ok and c == want["draw_count"] and bufs[k][0][:c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
-        print("ASYNC", int(ok), p.timings()["timeout_recoveries"])
-    except renderer_amd.MipError as e:
-        print("ERROR", e.code, p.timings()["timeout_recoveries"])
-'''
-    outs = {}
-    for mode in ("sync", "async2", "deep"):
-        out = subprocess.run([sys.executable, "-c", code, root, mode], capture_output=True, text=True, timeout=180)
-        assert out.returncode == 0, out.stderr[-3000:]
-        outs[mode] = [l for l in out.stdout.split("\n") if l and l.split()[0] in ("SYNC", "ASYNC", "ERROR")]
-    assert outs["sync"] and outs["sync"][0].split()[:3] == ["SYNC", "1", "1"], outs           # right outputs, one recovery
-    assert 0.4 < float(outs["sync"][0].split()[3]) < 20.0, outs                                  # ... after the 0.5 s of the bounded wait
-    assert outs["async2"] == ["ASYNC 1 1"], outs                                                 # both slots' frames issued again at mip_wait
-    assert outs["deep"] == ["ERROR -7 0"], outs                                                  # two frames per slot: reported, not repeated
+        assert p.timings()["graph_frames"] == 4, p.timings()
+        for k, (cmds, scal, _) in enumerate(sets):
+            count = int(scal[0].item())
+            assert count == wants[k]["draw_count"] and cmds[:count].cpu().numpy().tobytes() == wants[k]["draw_cmds"].tobytes(), k
+        helps.append(p.timings()["prefix_helps"])
+elif what == "skinned":
+    sk = scene.make_skinned_scene(1_000_000)
+    ws = oracle.run_skinned(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"], sk["meshes"], sk["skeleton"], sk["poses"], sk["planes"], sk["cam_pos"])
+    with renderer_amd.InstancePipeline(max_instances=sk["n"], max_meshes=1) as p:
+        p.set_mesh_table(sk["meshes"]); p.set_instances(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"])
+        p.set_skeleton(sk["skeleton"]["parent"], sk["skeleton"]["inverse_bind"], sk["skeleton"]["joint_box"]); p.set_poses(sk["poses"])
+        cmds = torch.zeros((sk["n"], 5), dtype=torch.int32, device=dev); scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        p.run_skinned(make_frame(sk["planes"], sk["cam_pos"]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
+        count = int(scal[0].item())
+        assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
+        helps.append(p.timings()["prefix_helps"])
+elif what == "views":
+    s = scene.make_scene(3, n=1_000_000)
+    cams = [np.array(c, np.float32) for c in ((0, 1, 2), (5, 1, 2), (-3, 2, 8))]
+    with renderer_amd.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"]); p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in cams:
+            cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev); scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        p.run_views([make_frame(s["planes"], c) for c in cams], [x[2] for x in sets])
+        p.wait()   # (prepared outputs are asynchronous by default)
+        for k, (cmds, scal, _) in enumerate(sets):
+            want = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], cams[k], threads=8, want=("draw_cmds",))
+            count = int(scal[0].item())
+            assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), k
+        helps.append(p.timings()["prefix_helps"])
+print("HELPS", " ".join(str(h) for h in helps))
+"""
+
+
+def _run_order_child(what, **env_add):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
+    env = dict(os.environ, **env_add)
+    env.pop("MIP_TUNE_ORDER", None)
+    out = subprocess.run([sys.executable, "-c", _ORDER_CHILD, root, what], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.split("\n") if l.startswith("HELPS")]
+    assert line, out.stdout
+    return [int(x) for x in line[0].split()[1:]]
+
+
+@pytest.mark.parametrize("tile_order", ["reverse", "scramble"])
+def test_any_dispatch_order_gives_the_same_bytes(tile_order):
+    """No kernel of the library depends on the order the hardware starts workgroups in. The diagnostic build numbers
+    the tiles by a PERMUTATION of the workgroup index — reversed (the first workgroups to run are the LAST tiles, every
+    one of which needs every earlier tile), or scrambled: a tile whose predecessors have not published after the
+    patient polls computes their aggregates itself (instance_kernel.hpp, resolve_prefix). Command list, count, index
+    total and bitmap equal the oracle's, in both kernel orders, both wire forms, with non-finite instances, for a
+    launch that is resident as a whole (nothing to help) and for one that is not (thousands of helps)."""
+    helps = _run_order_child("frames", MIP_DEBUG_TILE_ORDER=tile_order)
+    assert helps[0] == 0 and helps[1] == 0, helps            # 32 tiles: all resident, the predecessors publish in time
+    assert all(h > 0 for h in helps[2:]), helps              # 3 907 tiles: the early workgroups had to help themselves
+
+
+def test_any_dispatch_order_recorded_graphs_skinned_and_views():
+    """The same for frames replayed from recorded launch graphs (the helper reads its frame from the ring), a skinned
+    frame (per-instance boxes, the general kernel) and the multi-view kernel, tiles in reverse order."""
+    for what in ("graphs", "skinned", "views"):
+        helps = _run_order_child(what, MIP_DEBUG_TILE_ORDER="reverse")
+        assert helps[-1] > 0, (what, helps)
+
+
+def test_a_tile_that_never_publishes_is_helped():
+    """Fault injection (diagnostic build): tile 5 never publishes its aggregate (rounds 1-3: every later tile's bounded
+    wait expired after 0.5 s and the frame ended in MIP_ERR_TIMEOUT). Now the tiles that need it compute it: right
+    outputs, no error, and the count of helps says it happened."""
+    helps = _run_order_child("frames", MIP_DEBUG_SKIP_PUBLISH_TILE="5")
+    assert all(h > 0 for h in helps), helps
+
+
+def test_an_idle_gpu_needs_no_help(ra, oracle_mod):
+    """The product build on a GPU it has to itself: workgroups start in index order, nobody waits long enough to help
+    (MipTimings.prefix_helps stays 0) — self-help is the safety net, not the steady state."""
+    s = ra.scene.make_scene(3, n=1_000_000)
+    want = run_oracle(oracle_mod, s, threads=8)
+    with ra.InstancePipeline(max_instances=s["n"], max_meshes=64) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        for rep in range(20):
+            got = p.run_host(s["planes"], s["cam_pos"])
+        assert_parity(got, want, "1 M")
+        assert p.timings()["prefix_helps"] == 0, p.timings()
 
 
 def test_frames_in_flight_rotate_independent_state(ra, oracle_mod):

@@ -234,9 +234,9 @@ def _recv_exact(conn, k):
     return bytes(out)
 
 
-def test_views_in_ordered_tiles_mode(ra, oracle_mod):
-    """A context that must not depend on dispatch order (MIP_CFG_ORDERED_TILES, or after a MIP_ERR_TIMEOUT)
-    runs mip_run_views as one ticketed frame per view: same bytes as the multi-view launch."""
+def test_views_with_the_ignored_ordered_tiles_flag(ra, oracle_mod):
+    """(ABI <= 3: a context in ordered-tiles mode ran one ticketed frame per view; the flag is ignored now)
+    five views (two launches of the multi-view kernel): each equal to the oracle's frame for that view."""
     import torch
 
     from renderer_amd.pipeline import make_frame

@@ -116,9 +116,9 @@ def test_wire_list_is_the_command_list(ra, oracle_mod, n):
                          culled_index_buffer=body.data_ptr(), culled_index_capacity=4)
 
 
-def test_wire_form_in_ordered_tiles_mode_and_with_non_finite_instances(ra, oracle_mod, monkeypatch):
-    """The wire form is a template parameter of the frame kernel: the ticketed (ordered tiles) and the general (literal
-    arithmetic) instantiations carry it too."""
+def test_wire_form_with_non_finite_instances_and_the_ignored_ordered_tiles_flag(ra, oracle_mod, monkeypatch):
+    """The wire form is a template parameter of the frame kernel: the general (literal arithmetic) instantiation carries it
+    too. (MIP_CFG_ORDERED_TILES, which up to ABI 3 selected a ticketed instantiation, is accepted and changes nothing.)"""
     import torch
 
     from cpu_pipeline import decode_wire, unpack_wire
@@ -274,37 +274,21 @@ with renderer_amd.InstancePipeline(max_instances=hi - lo, max_meshes=64) as p:
         assert merged[:total].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
     # `frames` asynchronous frames back to back: while this rank's collective kernel of frame k spin-waits on the
     # device for its peers, the peers' shard kernels of frame k (and this rank's of k + 1, queued behind) need the
-    # same GPU. EVERY rank issues exactly the same sequence of collectives whatever happens locally: a rank whose
-    # frame timed out reports it (the context falls back to ordered tiles by itself) and goes on.
+    # same GPU. No frame may fail: a shard kernel whose predecessors' tiles cannot start (the peers' spinning
+    # workgroups hold the compute units) computes what it needs itself (MipTimings.prefix_helps says whether it had to).
     for k in range(frames):
         p.run_sharded(frame, merged.data_ptr(), count.data_ptr(), async_=True)
         if k % 8 == 7:
-            try:
-                p.wait()
-            except renderer_amd.MipError as e:
-                assert e.code == -7, e
-                timeouts += 1
-    try:
-        p.wait()
-    except renderer_amd.MipError as e:
-        assert e.code == -7, e
-        timeouts += 1
-    # whatever happened above, the frames after it are right on every rank (no timeout: straight away; after a
-    # timeout: in ordered-tiles mode). Two settle frames let a peer that timed out in the last batch catch up.
-    ok = 0
-    for k in range(4):
-        try:
-            p.run_sharded(frame, merged.data_ptr(), count.data_ptr())
-            if k >= 2:
-                check(f"settled frame {k}")
-                ok += 1
-        except renderer_amd.MipError as e:
-            assert e.code == -7, e
-            timeouts += 1
-    assert ok >= 1
+            p.wait()
+            check(f"frame {k}")
+    p.wait()
+    for k in range(2):
+        p.run_sharded(frame, merged.data_ptr(), count.data_ptr())
+        check(f"synchronous frame {k}")
+    timeouts = p.timings()["prefix_helps"]
     sent = p.timings()["sharded_bytes_sent"]
     p.comm_destroy()
-open(out_path, "w").write(f"ok timeouts={timeouts} sent={sent}")
+open(out_path, "w").write(f"ok helps={timeouts} sent={sent}")
 '''
 
 
@@ -324,9 +308,9 @@ def test_sharded_frames_beside_a_collective_that_spin_waits_on_the_device(ra, tm
     """The co-tenant shape of DESIGN.md section 4: the collective is a KERNEL of persistent workgroups that spin-wait on
     the device for the peers (tests/fake_ccl/spin_rccl.hip), enqueued asynchronously like RCCL's, and the ranks —
     one process each — share this box's one GPU, so shard kernels of one rank run beside spinning collective
-    workgroups of another. Must end with every rank holding the unsharded oracle's list: without a timeout, or —
-    if the dispatch-order assumption breaks — with MIP_ERR_TIMEOUT reported and the frames after it right (the
-    context switches itself to ordered tiles). Never a hang, never a silent wrong list."""
+    workgroups of another. Every frame of every rank must equal the unsharded oracle's list — no error, no hang: a
+    tile whose predecessor cannot start computes that predecessor's aggregate itself (the note printed below carries
+    each rank's MipTimings.prefix_helps)."""
     fake = _build_double(tmp_path, "spin_rccl")
     env = dict(os.environ, MIP_COMM_LIBRARY=fake, SPIN_CCL_WORKGROUPS=str(workgroups))
     id_path = str(tmp_path / "uid")
@@ -609,43 +593,31 @@ def test_external_semaphore_entry_points(ra, oracle_mod):
         open(os.path.join(out, "external_semaphore_notes.txt"), "w").write("\n".join(notes) + "\n")
 
 
-@pytest.mark.parametrize("min_tiles", ["0", "default"])
-def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
-    """MIP_CFG_ORDERED_TILES on large launches: three launches none of which waits for another workgroup (the frame kernel
-    without commands leaving one pair per tile, the scan of the pairs by groups of 64 tiles, the commands from the visibility
-    bitmap: emit_kernel.hpp) instead of one ticket per tile. Same bytes as the default kernel: plain frames at sizes either
-    side of the switch, non-finite instances (literal tier), both wire forms, bases, host outputs (with and without a bitmap
-    of the caller's), the per-triangle stage (its scratch list, count and source offsets), a skinned frame (box override) and
-    culled views. min_tiles=0 forces the mode onto every launch."""
+def test_bases_non_finite_and_wire_forms_across_launch_sizes(ra, oracle_mod):
+    """(Round 3 ran this sweep against the three wait-free launches of the ordered-tiles mode, which is gone: every launch is
+    order-independent now.) One frame at sizes either side of every switch the host takes — one tile, a partial tile, the
+    commands-first / stores-first crossover, more tiles than are resident — with non-finite instances (the general kernel),
+    instance and index bases, host outputs, both wire forms and plain device outputs: all equal to the oracle's bytes."""
     import torch
 
     from cpu_pipeline import decode_wire, unpack_wire
+    from helpers import assert_parity
     from renderer_amd.pipeline import make_frame, wire_body_bytes
 
-    if min_tiles != "default":
-        monkeypatch.setenv("MIP_TUNE_THREE_PASS_MIN_TILES", min_tiles)
     dev = torch.device("cuda", 0)
-    # launches of up to 4 096 tiles have no scan launch (the last launch sums the earlier tiles' pairs itself): 1 200 003 instances
-    # take the scan, and so does 70 001 with the switch forced (a partial last group of 64 tiles)
-    for n in ((1, 255, 4_097, 70_001, -70_001) if min_tiles == "0" else (40_960, 40_961, 131_073, 1_200_003)):
-        if n < 0:
-            n = -n
-            monkeypatch.setenv("MIP_TUNE_EMIT_SELF_PREFIX_TILES", "0")
+    for n in (1, 255, 4_097, 40_961, 131_073, 1_200_003):
         s = ra.scene.make_scene(3, n=n)
         if n > 300:
             s["pos"][17] = np.nan
             s["scale"][200] = np.inf
         want = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=8,
                               first_instance_base=11, first_index_base=5)
-        with ra.InstancePipeline(max_instances=n, max_meshes=64, ordered_tiles=True) as p:
+        with ra.InstancePipeline(max_instances=n, max_meshes=64) as p:
             p.set_mesh_table(s["meshes"])
             p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
             for rep in range(2):
                 got = p.run_host(s["planes"], s["cam_pos"], first_instance_base=11, first_index_base=5)
-                from helpers import assert_parity
-                assert_parity(got, want, f"three-pass n={n} rep={rep}")
-            expect_three = 2 if (min_tiles == "0" or (n + 255) // 256 > 160) else 0
-            assert p.timings()["three_pass_frames"] == expect_three, (n, p.timings()["three_pass_frames"])
+                assert_parity(got, want, f"n={n} rep={rep}")
             body = torch.zeros(wire_body_bytes(n) // 4, dtype=torch.int32, device=dev)
             scal = torch.zeros(8, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
@@ -654,7 +626,6 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
             count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
             assert count == want["draw_count"] and total == want["draw_index_total"]
             assert decode_wire(body.cpu().numpy().view(np.uint32), count, s["meshes"]).tobytes() == want["draw_cmds"].tobytes(), n
-            # the packed wire form, and device outputs WITHOUT a bitmap (the library's scratch bitmap feeds the last launch)
             body.zero_()
             scal.zero_()
             torch.cuda.synchronize()
@@ -669,54 +640,10 @@ def test_ordered_tiles_three_pass_mode(ra, oracle_mod, monkeypatch, min_tiles):
                          draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
             assert [int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist()] == [count, total]
             assert cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), n
-    if min_tiles != "0":
-        # frames issued from compiled code (mip_run_many) take the same path: large ordered launches are not recorded as graphs
-        s = ra.scene.make_scene(3, n=300_000)
-        want = run_oracle(oracle_mod, s, threads=8, want=("draw_cmds",))
-        with ra.InstancePipeline(max_instances=s["n"], max_meshes=64, frames_in_flight=2, ordered_tiles=True) as p:
-            p.set_mesh_table(s["meshes"])
-            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
-            sets = []
-            for _ in range(2):
-                cmds = torch.zeros((s["n"], 5), dtype=torch.int32, device=dev)
-                scal = torch.zeros(8, dtype=torch.int32, device=dev)
-                sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
-            torch.cuda.synchronize()
-            p.run_many(make_frame(s["planes"], s["cam_pos"]), [x[2] for x in sets], 130)
-            p.wait()
-            t = p.timings()
-            assert t["graph_frames"] == 0 and t["three_pass_frames"] == 130
-            for cmds, scal, _ in sets:
-                count = int(scal[0].item())
-                assert count == want["draw_count"] and cmds[:count].cpu().numpy().tobytes() == want["draw_cmds"].tobytes()
-        return
-    # the per-triangle stage behind a three-pass frame
-    from test_gpu_triangles import _oracle, _run_gpu
-    monkeypatch.setenv("MIP_TUNE_ORDERED_TILES", "1")
-    s = ra.scene.make_scene(3, n=3000)
-    vertices, indices = ra.scene.make_geometry(s["meshes"])
-    pv = ra.scene.default_pv()
-    r0 = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
-    capacity = r0["draw_index_total"] + 3
-    r, want_cmds, want_out = _oracle(oracle_mod, s, vertices, indices, pv, capacity)
-    got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, frames=2)
-    assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes() and np.array_equal(got_out, want_out)
-    # a skinned frame (per-instance box override in both passes)
-    sk = ra.scene.make_skinned_scene(5000)
-    ws = oracle_mod.run_skinned(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"], sk["meshes"], sk["skeleton"], sk["poses"], sk["planes"], sk["cam_pos"])
-    with ra.InstancePipeline(max_instances=5000, max_meshes=1, ordered_tiles=True) as p:
-        p.set_mesh_table(sk["meshes"])
-        p.set_instances(sk["pos"], sk["rot"], sk["scale"], sk["mesh_id"])
-        p.set_skeleton(sk["skeleton"]["parent"], sk["skeleton"]["inverse_bind"], sk["skeleton"]["joint_box"])
-        p.set_poses(sk["poses"])
-        cmds = torch.zeros((5000, 5), dtype=torch.int32, device=dev)
-        scal = torch.zeros(8, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        for _ in range(2):
-            p.run_skinned(make_frame(sk["planes"], sk["cam_pos"]), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)
-        count = int(scal[0].item())
-        assert count == ws["draw_count"] and cmds[:count].cpu().numpy().tobytes() == ws["draw_cmds"].tobytes()
-        assert p.timings()["three_pass_frames"] == 2
+            assert p.timings()["prefix_helps"] == 0
+            # a draw list that is only 4-byte aligned is fine for 20-byte commands and refused for the wire forms
+            with pytest.raises(ra.MipError):
+                p.run_device(make_frame(s["planes"], s["cam_pos"]), draw_cmds=body.data_ptr() + 4, draw_count=scal.data_ptr(), wire=True)
 
 
 def test_kernel_wire_bytes_equal_the_committed_fixture(ra):
