@@ -380,13 +380,13 @@ def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, str
     if doc and doc["counters_per_launch"].get("SQ_INSTS_VALU"):
         valu = doc["counters_per_launch"]["SQ_INSTS_VALU"]
         row["roofline"] = {
-            "bound": "valu", "kernel": "mip_cull_views_kernel", "achieved": valu / (ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S,
+            "bound": "valu", "kernel": "mip_cull_views_kernel", "achieved": valu / (ms * 1e-3), "peak": VALU_PEAK_WAVE_INSTR_PER_S, "peak_source": VALU_PEAK_SOURCE,
             "unit": "wave-instructions/s", "frac": valu / (ms * 1e-3) / VALU_PEAK_WAVE_INSTR_PER_S,
             "valu_wave_instructions_per_launch": valu, "kernel_ms": ms, "kernel_ms_under_pmc": doc["kernel_ns_under_pmc"] * 1e-6,
             "traffic": doc.get("hbm_bytes_per_launch"), "algorithmic_bytes_per_launch": nbytes, "source": src,
-            "note": "SQ_INSTS_VALU per launch (committed PMC pass of this kernel source) / this run's launch time; peak = one wave64 f32 "
-                    "VALU instruction per 4 cycles per SIMD (the kernel's translation unit is built without the SLP vectoriser: no "
-                    "packed instructions)",
+            "note": "SQ_INSTS_VALU per launch (committed PMC pass of this kernel source) / this run's launch time; peak = the MEASURED issue "
+                    "ceiling of plain f32 wave64 instructions (peak_source; the kernel's translation unit is built without the SLP "
+                    "vectoriser: no packed instructions)",
         }
     return row
 
@@ -432,11 +432,13 @@ def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_
     }
 
 
-# One SIMD issues one wave64 f32 VALU instruction (v_mul_f32 / v_add_f32 ...) per 4 cycles (MI355X_MICROARCH.md, per-instruction
-# cycle constants: "v_add_f32 / v_fma_f32 / v_max3_f32 4"); a packed v_pk_*_f32 takes two such passes. 1024 SIMDs at 2.4 GHz.
-# (Round 2 priced this kernel against one instruction per 2 cycles, which no f32 instruction of the kernel can reach: its
-# 0.34 is 0.68 on this scale.)
-VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.0
+# The VALU issue ceiling, MEASURED (tools/micro/valu_issue.hip -> profiles/r04_valu_issue.txt): with every CU busy and 8 waves
+# per SIMD the chip retires 9.6-10.0e11 plain f32 wave64 instructions per second (v_mul / v_add / v_fma and their mix) — one
+# per 2 cycles per SIMD at the 2.0-2.25 GHz the clock settles at under that load (the runtime reports 2.4 GHz); one wave
+# alone issues one per 4.5 cycles, which is the constant round 3 mistook for the SIMD's ceiling (its 6.1e11 "peak" was
+# exceeded by a leg that printed frac 1.002); a packed v_pk_*_f32 counts as two. Round 2's scale was the right one.
+VALU_PEAK_WAVE_INSTR_PER_S = 9.8e11
+VALU_PEAK_SOURCE = "profiles/r04_valu_issue.txt: plain f32, 8 waves per SIMD, every CU busy, whole-launch rate; clock under load 2.0-2.25 GHz"
 
 
 def triangle_pmc(config, n, ordering="rows"):
@@ -502,10 +504,13 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
         kern_ns = list(doc["kernel_ns_under_pmc"].values())[0]
         row["roofline"] = {
             "bound": "valu", "kernel": list(doc["kernel_ns_under_pmc"].keys())[0], "achieved": valu / (kern_ns * 1e-9),
-            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instructions/s", "frac": valu / (kern_ns * 1e-9) / VALU_PEAK_WAVE_INSTR_PER_S,
+            "peak": VALU_PEAK_WAVE_INSTR_PER_S, "peak_source": VALU_PEAK_SOURCE, "unit": "wave-instructions/s",
+            "frac": valu / (kern_ns * 1e-9) / VALU_PEAK_WAVE_INSTR_PER_S,
             "valu_wave_instructions_per_launch": valu, "kernel_ms": kern_ns * 1e-6, "source": src,
-            "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; peak = one wave64 f32 VALU instruction per "
-                    "4 cycles per SIMD (the kernel has no packed instructions: its translation unit is built without the SLP vectoriser)",
+            "note": "SQ_INSTS_VALU per launch / the kernel's duration in the same rocprofv3 pass; peak = the MEASURED issue ceiling of plain "
+                    "f32 wave64 instructions, one per 2 cycles per SIMD at the clock the chip holds under load (peak_source); the kernel has no "
+                    "packed instructions (its translation unit is built without the SLP vectoriser). Round 3 printed 0.98 here against a ceiling "
+                    "of one instruction per 4 cycles, which is what ONE wave sustains, not what the SIMD does",
         }
     if with_cpu:
         import oracle

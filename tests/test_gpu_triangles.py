@@ -38,6 +38,7 @@ def _run_gpu(ra, s, vertices, indices, pv, capacity, frames=1, first_instance_ba
                          culled_index_capacity=capacity)
         count, total = (int(x) & 0xFFFFFFFF for x in scal[:2].cpu().tolist())
         got_cmds = cmds[:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+        _run_gpu.last_timings = p.timings()
         return got_cmds, count, total, out.cpu().numpy().view(np.uint32)
 
 
@@ -196,3 +197,40 @@ def test_triangle_cull_at_baseline_sizes(ra, oracle_mod, config, n):
     assert np.array_equal(got_out, want_out)
     survivors = int(want_cmds["indexCount"].astype(np.int64).sum())
     assert 0.2 < survivors / int(r["draw_cmds"]["indexCount"].astype(np.int64).sum()) < 0.8
+
+
+def test_parts_kernel_in_reverse_order_helps_itself(oracle_mod):
+    """The parts kernel (16 work items per command, a part writes its survivors behind those of the earlier parts of its
+    command) with the work items dealt from the LAST one down (diagnostic build): every part finds its predecessors
+    unpublished, counts their survivors itself and the stream still equals the oracle's — no wait depends on another
+    workgroup ever running (rounds 2-3: a bounded wait, MIP_ERR_TIMEOUT and the kernel switched off for the context)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
+    code = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
+os.environ["MIP_TUNE_TRI_PARTS_MAX"] = "100000000"
+os.environ["MIP_DEBUG_TILE_ORDER"] = "reverse"
+import numpy as np
+import oracle, renderer_amd
+from test_gpu_triangles import _oracle, _run_gpu
+import torch
+for config, n in ((3, 3000), (2, 700)):
+    s = renderer_amd.scene.make_scene(config, n=n)
+    vertices, indices = renderer_amd.scene.make_geometry(s["meshes"])
+    pv = renderer_amd.scene.default_pv()
+    r0 = oracle.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], want=("draw_cmds",))
+    capacity = r0["draw_index_total"] + 3
+    r, want_cmds, want_out = _oracle(oracle, s, vertices, indices, pv, capacity)
+    got_cmds, count, total, got_out = _run_gpu(renderer_amd, s, vertices, indices, pv, capacity, frames=2)
+    assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes() and np.array_equal(got_out, want_out), (config, n)
+    assert _run_gpu.last_timings["prefix_helps"] > 0, _run_gpu.last_timings
+print("PARTS OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PARTS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
