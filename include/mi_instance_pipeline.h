@@ -71,7 +71,7 @@ extern "C" {
                               * command instead of 20) — what a rank sends through the all-gather; draw_count and
                               * draw_index_total as usual. Not with culled_index_buffer (the wire form carries no
                               * indexCount: it is the mesh table's). mip_merge_wire_lists expands it again. */
-#define MIP_OUT_WIRE_PACKED 0x8u /* with MIP_OUT_WIRE: the PACKED wire form below, 4.06 B per command — one 32-bit record
+#define MIP_OUT_WIRE_PACKED 0x8u /* with MIP_OUT_WIRE: the PACKED wire form below, 4.25 B per command — one 32-bit record
                               * {instance index in the frame | mesh_id << index_bits | lod << 31}. Only while the
                               * context's instance count fits: n <= 1 << mip_wire_index_bits(n_meshes), else
                               * MIP_ERR_INVALID_ARGUMENT. mip_merge_wire_lists_packed expands it. */
@@ -211,29 +211,34 @@ typedef struct MipShardHeader {
  * vertexOffset come from the mesh table every rank holds, instanceCount is 1 (generate_work.comp:63).
  * The wire form therefore carries per command the 8-byte record
  *     { firstInstance, mesh_id | lod << 31 }            lod = 0 or 1 (pick_lod, helpers.rs:3-11)
- * in blocks of MIP_WIRE_BLOCK_COMMANDS records, each block behind a 16-byte block header whose
- * first word is the firstIndex of the block's first command (relative to the shard, plus the
- * frame's first_index_base, as the 20-byte form has it); the firstIndex of the others is that plus
- * the index_len of the records in front of them within the block. Block b of a list lives at byte
- * b * MIP_WIRE_BLOCK_BYTES of the body; a list cut after any whole number of blocks is a valid
- * shorter list, which is what lets a rank send a tightened slice of it. */
+ * in blocks of MIP_WIRE_BLOCK_COMMANDS records, each block behind a 16-byte block header of FOUR
+ * words: word q is the firstIndex of the block's record MIP_WIRE_SUB_BLOCK_COMMANDS * q (relative to
+ * the shard, plus the frame's first_index_base, as the 20-byte form has it; a word whose record does
+ * not exist is unspecified). The firstIndex of the other records is their anchor plus the index_len of
+ * the records between the anchor and them. (ABI <= 3 anchored only record 0 of a block; 64-record
+ * sub-blocks let one wave of the merge kernel expand its share without talking to the others.)
+ * Block b of a list lives at byte b * MIP_WIRE_BLOCK_BYTES of the body; a list cut after any whole
+ * number of blocks is a valid shorter list, which is what lets a rank send a tightened slice of it. */
 #define MIP_WIRE_BLOCK_COMMANDS 256u
+#define MIP_WIRE_SUB_BLOCK_COMMANDS 64u
 #define MIP_WIRE_BLOCK_HEADER_BYTES 16u
 #define MIP_WIRE_RECORD_BYTES 8u
 #define MIP_WIRE_BLOCK_BYTES (MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_RECORD_BYTES) /* 2064 */
 /* bytes of the body of a wire list with room for `capacity` commands (whole blocks) */
 #define MIP_WIRE_BODY_BYTES(capacity) \
   ((((uint64_t)(capacity) + MIP_WIRE_BLOCK_COMMANDS - 1u) / MIP_WIRE_BLOCK_COMMANDS) * MIP_WIRE_BLOCK_BYTES)
-/* The PACKED wire form (MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED): the same blocks with ONE 32-bit record per command,
+/* The PACKED wire form (MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED): ONE 32-bit record per command,
  *     instance_index | mesh_id << index_bits | lod << 31,      instance_index = firstInstance - first_instance_base,
- * and a block header {firstIndex of the block's first command, the frame's first_instance_base, index_bits, 0}.
+ * in blocks of MIP_WIRE_PACKED_BLOCK_COMMANDS = 64 records, each behind a self-describing 16-byte header
+ * {firstIndex of the block's first command, the frame's first_instance_base, index_bits, 0}: 4.25 B per command.
  * index_bits = mip_wire_index_bits(n_meshes) = 31 - ceil(log2(n_meshes)) is what the mesh ids leave of the word, so the
  * form exists for frames of at most 1 << index_bits instances (64 meshes: 33 M; 1 024 meshes: 2 M) — every rank of an
  * exchange derives the same answer from the replicated mesh table and the largest shard. */
 #define MIP_WIRE_PACKED_RECORD_BYTES 4u
-#define MIP_WIRE_PACKED_BLOCK_BYTES (MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES) /* 1040 */
+#define MIP_WIRE_PACKED_BLOCK_COMMANDS 64u
+#define MIP_WIRE_PACKED_BLOCK_BYTES (MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_PACKED_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES) /* 272 */
 #define MIP_WIRE_PACKED_BODY_BYTES(capacity) \
-  ((((uint64_t)(capacity) + MIP_WIRE_BLOCK_COMMANDS - 1u) / MIP_WIRE_BLOCK_COMMANDS) * MIP_WIRE_PACKED_BLOCK_BYTES)
+  ((((uint64_t)(capacity) + MIP_WIRE_PACKED_BLOCK_COMMANDS - 1u) / MIP_WIRE_PACKED_BLOCK_COMMANDS) * MIP_WIRE_PACKED_BLOCK_BYTES)
 /* bits of a packed record left for the instance index by a mesh table of n_meshes entries (pure function) */
 uint32_t mip_wire_index_bits(uint32_t n_meshes);
 
@@ -411,7 +416,7 @@ int32_t mip_merge_wire_lists_packed(MipContext* ctx, const void* chunks, uint32_
 /* ---- sharded scenes without a Python host: RCCL straight from the library ------------------
  * librccl.so.1 is opened with dlopen on first use, so single-GPU hosts do not need it. The
  * exchange is the one of SURVEY.md §8e: every rank runs its shard, ONE ncclAllGather moves the
- * fixed-size chunks [MipShardHeader | wire body for chunk_capacity commands: 4.06 B each (packed form; 8.06 B when the
+ * fixed-size chunks [MipShardHeader | wire body for chunk_capacity commands: 4.25 B each (packed form; 8.06 B when the
  * largest shard does not fit a packed record) instead of 20, see MIP_OUT_WIRE], the merge kernel expands and concatenates them. Needs a context with one frame in flight. */
 #define MIP_COMM_ID_BYTES 128u
 

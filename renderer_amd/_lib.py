@@ -25,11 +25,13 @@ MIP_OUT_ASYNC = 0x2
 MIP_OUT_WIRE = 0x4
 MIP_OUT_WIRE_PACKED = 0x8
 MIP_WIRE_BLOCK_COMMANDS = 256
+MIP_WIRE_SUB_BLOCK_COMMANDS = 64
 MIP_WIRE_BLOCK_HEADER_BYTES = 16
 MIP_WIRE_RECORD_BYTES = 8
 MIP_WIRE_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_RECORD_BYTES
 MIP_WIRE_PACKED_RECORD_BYTES = 4
-MIP_WIRE_PACKED_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES
+MIP_WIRE_PACKED_BLOCK_COMMANDS = 64
+MIP_WIRE_PACKED_BLOCK_BYTES = MIP_WIRE_BLOCK_HEADER_BYTES + MIP_WIRE_PACKED_BLOCK_COMMANDS * MIP_WIRE_PACKED_RECORD_BYTES
 MIP_MAX_LODS = 6
 MIP_SEMAPHORE_BINARY = 0
 MIP_SEMAPHORE_TIMELINE = 1

@@ -126,7 +126,8 @@ static uint64_t wire_stride_bytes(uint64_t capacity, bool packed) {
 static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t n_chunks, uint64_t chunk_stride_bytes,
                                   uint32_t chunk_capacity, void* out_cmds, uint32_t* out_count, bool packed) {
   static_assert(MIP_WIRE_BLOCK_COMMANDS == mip::kWireBlockCmds && MIP_WIRE_BLOCK_BYTES == mip::kWireBlockWords * 4u &&
-                MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u && MIP_WIRE_PACKED_BLOCK_BYTES == mip::kWirePackedBlockWords * 4u,
+                MIP_WIRE_BLOCK_HEADER_BYTES == mip::kWireBlockHeaderWords * 4u && MIP_WIRE_SUB_BLOCK_COMMANDS == mip::kWireSubBlock &&
+                MIP_WIRE_PACKED_BLOCK_COMMANDS == mip::kWirePackedBlockCmds && MIP_WIRE_PACKED_BLOCK_BYTES == mip::kWirePackedBlockWords * 4u,
                 "wire layout: header and kernels agree");
   mip::MergeWireArgs a{};
   a.chunks = (const unsigned char*)chunks;
@@ -139,8 +140,9 @@ static int32_t enqueue_merge_wire(MipContext* ctx, const void* chunks, uint32_t 
   a.meshes = ctx->d_meshes;
   a.mesh_draw = ctx->d_mesh_draw;
   a.n_meshes = ctx->m;
-  // one workgroup expands one block of 256 records at a time; sized for the blocks the chunks can hold
-  const uint64_t max_blocks = ((uint64_t)chunk_capacity + mip::kWireBlockCmds - 1) / mip::kWireBlockCmds * n_chunks;
+  // one WAVE expands one group of 256 records at a time (four waves per workgroup); sized for the groups the chunks can hold
+  const uint64_t max_groups = ((uint64_t)chunk_capacity + mip::kMergeGroupCmds - 1) / mip::kMergeGroupCmds * n_chunks;
+  const uint64_t max_blocks = (max_groups + 3) / 4;
   const uint32_t grid_cap = std::getenv("MIP_TUNE_MERGE_GRID") ? (uint32_t)std::atoi(std::getenv("MIP_TUNE_MERGE_GRID")) : 256u * 8u;
   uint32_t blocks = max_blocks > grid_cap ? grid_cap : (uint32_t)max_blocks;
   if (blocks < 1) blocks = 1;
@@ -161,7 +163,8 @@ static int32_t merge_wire_lists(MipContext* ctx, const void* chunks, uint32_t n_
   if ((uintptr_t)chunks & 15u)  // block headers and records are read with 16-byte loads
     return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "wire chunks must be 16-byte aligned");
   if (chunk_capacity == 0) {  // what the stride holds, in whole blocks
-    const uint64_t fits = (chunk_stride_bytes - sizeof(MipShardHeader)) / (packed ? MIP_WIRE_PACKED_BLOCK_BYTES : MIP_WIRE_BLOCK_BYTES) * MIP_WIRE_BLOCK_COMMANDS;
+    const uint64_t fits = packed ? (chunk_stride_bytes - sizeof(MipShardHeader)) / MIP_WIRE_PACKED_BLOCK_BYTES * MIP_WIRE_PACKED_BLOCK_COMMANDS
+                                 : (chunk_stride_bytes - sizeof(MipShardHeader)) / MIP_WIRE_BLOCK_BYTES * MIP_WIRE_BLOCK_COMMANDS;
     chunk_capacity = fits > 0x3fffffffull ? 0x3fffffffu : (uint32_t)fits;
   }
   if ((chunk_stride_bytes & 15u) || sizeof(MipShardHeader) + wire_body_bytes(chunk_capacity, packed) > chunk_stride_bytes)

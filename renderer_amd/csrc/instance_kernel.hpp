@@ -702,11 +702,16 @@ static __global__ __launch_bounds__(256) __attribute__((unused)) void mip_count_
 }
 
 // The wire form of a shard's draw list (include/mi_instance_pipeline.h, MIP_OUT_WIRE): blocks of 256 8-byte records
-// {firstInstance, mesh | lod << 31}, each block behind a 16-byte header whose first word is the firstIndex of the
-// block's first command. 8.06 B per command instead of 20 through the all-gather; mip_merge_wire_lists_kernel
-// (merge_kernel.hpp) expands it against the replicated mesh table.
+// {firstInstance, mesh | lod << 31}, each block behind a 16-byte header of FOUR firstIndex words — word q is the firstIndex of
+// the block's record 64 q, so every 64 records ("sub-block": what one wave of the merge kernel expands with one DPP scan, on
+// its own, without a barrier) carry their own anchor. 8.06 B per command instead of 20 through the all-gather;
+// mip_merge_wire_lists_kernel (merge_kernel.hpp) expands it against the replicated mesh table.
+// (ABI 3 anchored only record 0 of a block: the merge then needed the whole workgroup, two barriers and an LDS prefix per block.)
+constexpr uint32_t kWireSubBlock = 64;
 constexpr uint32_t kWireBlockCmds = 256, kWireBlockHeaderWords = 4, kWireBlockWords = kWireBlockHeaderWords + 2 * kWireBlockCmds;
-constexpr uint32_t kWirePackedBlockWords = kWireBlockHeaderWords + kWireBlockCmds;  // MIP_OUT_WIRE_PACKED: one word per record
+// MIP_OUT_WIRE_PACKED: one word per record in blocks of 64 = one sub-block behind its own self-describing 16-byte header
+// {firstIndex, first_instance_base, index_bits, 0}: 4.25 B per command
+constexpr uint32_t kWirePackedBlockCmds = kWireSubBlock, kWirePackedBlockWords = kWireBlockHeaderWords + kWirePackedBlockCmds;
 
 // Copy-out of a tile's `tile_count` staged commands (LDS, kCmdLdsWords each: [2] tile-relative firstIndex,
 // [4] firstInstance, [5] mesh | lod << 31) as wire records at list positions base_count .. ; run by one wave.
@@ -717,7 +722,7 @@ __device__ __forceinline__ void wire_copy_out(uint32_t* body, const uint32_t* s_
     uint32_t* b = body + (size_t)block * kWireBlockWords;
     const uint32_t* c = &s_cmd[k * kCmdLdsWords];
     *reinterpret_cast<uint2*>(b + kWireBlockHeaderWords + 2u * slot) = make_uint2(c[4], c[5]);
-    if (slot == 0u) *reinterpret_cast<uint4*>(b) = make_uint4(c[2] + first_index_add, 0u, 0u, 0u);
+    if (slot % kWireSubBlock == 0u) b[slot / kWireSubBlock] = c[2] + first_index_add;  // this record anchors its sub-block
   }
 }
 
@@ -727,7 +732,7 @@ __device__ __forceinline__ void wire_packed_copy_out(uint32_t* body, const uint3
                                                      uint32_t first_index_add, uint32_t tile_count, uint32_t first_instance_base,
                                                      uint32_t index_bits) {
   for (uint32_t k = lane; k < tile_count; k += 64u) {
-    const uint32_t g = base_count + k, block = g / kWireBlockCmds, slot = g % kWireBlockCmds;
+    const uint32_t g = base_count + k, block = g / kWirePackedBlockCmds, slot = g % kWirePackedBlockCmds;
     uint32_t* b = body + (size_t)block * kWirePackedBlockWords;
     const uint32_t* c = &s_cmd[k * kCmdLdsWords];
     b[kWireBlockHeaderWords + slot] = (c[4] - first_instance_base) | ((c[5] & 0x7fffffffu) << index_bits) | (c[5] & 0x80000000u);

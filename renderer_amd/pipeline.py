@@ -47,9 +47,10 @@ def wire_index_bits(n_meshes):
 
 
 def wire_body_bytes(capacity, packed=False):
-    """MIP_WIRE_BODY_BYTES / MIP_WIRE_PACKED_BODY_BYTES: whole blocks of 256 records (8 bytes each, 4 in the packed form)
-    behind a 16-byte block header."""
-    blocks = (int(capacity) + _lib.MIP_WIRE_BLOCK_COMMANDS - 1) // _lib.MIP_WIRE_BLOCK_COMMANDS
+    """MIP_WIRE_BODY_BYTES / MIP_WIRE_PACKED_BODY_BYTES: whole blocks of 256 8-byte records, or of 64 packed 4-byte records,
+    each behind a 16-byte block header."""
+    per = _lib.MIP_WIRE_PACKED_BLOCK_COMMANDS if packed else _lib.MIP_WIRE_BLOCK_COMMANDS
+    blocks = (int(capacity) + per - 1) // per
     return blocks * (_lib.MIP_WIRE_PACKED_BLOCK_BYTES if packed else _lib.MIP_WIRE_BLOCK_BYTES)
 
 

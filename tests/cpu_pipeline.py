@@ -9,20 +9,25 @@ import oracle
 from renderer_amd.pipeline import DRAW_CMD_DTYPE, SHARD_HEADER_BYTES, wire_body_bytes, wire_form, wire_index_bits
 
 WIRE_BLOCK = 256            # MIP_WIRE_BLOCK_COMMANDS
+WIRE_SUB = 64               # MIP_WIRE_SUB_BLOCK_COMMANDS: every 64 records carry their own firstIndex anchor
 WIRE_BLOCK_WORDS = 4 + 2 * WIRE_BLOCK
-WIRE_PACKED_BLOCK_WORDS = 4 + WIRE_BLOCK   # MIP_OUT_WIRE_PACKED: one word per record
+WIRE_PACKED_BLOCK = 64      # MIP_WIRE_PACKED_BLOCK_COMMANDS
+WIRE_PACKED_BLOCK_WORDS = 4 + WIRE_PACKED_BLOCK   # MIP_OUT_WIRE_PACKED: one word per record
 
 
 def encode_wire(cmds, mesh_of_cmd, far_of_cmd):
     """The wire form of a 20-byte command list (include/mi_instance_pipeline.h, MIP_OUT_WIRE), restated in numpy:
-    blocks of 256 records {firstInstance, mesh | far << 31}, each behind a 16-byte header whose first word is the
-    firstIndex of the block's first command. Returns the body as uint32 words (whole blocks; unused slots zero)."""
+    blocks of 256 records {firstInstance, mesh | far << 31}, each behind a 16-byte header whose word q is the firstIndex of
+    the block's record 64 q. Returns the body as uint32 words (whole blocks; unused slots and anchors zero)."""
     n = len(cmds)
     blocks = (n + WIRE_BLOCK - 1) // WIRE_BLOCK
     body = np.zeros(blocks * WIRE_BLOCK_WORDS, np.uint32)
     v = body.reshape(blocks, WIRE_BLOCK_WORDS)
     if n:
-        v[:, 0] = cmds["firstIndex"][::WIRE_BLOCK]
+        anchors = np.zeros(blocks * 4, np.uint32)
+        a = cmds["firstIndex"][::WIRE_SUB]
+        anchors[: len(a)] = a
+        v[:, :4] = anchors.reshape(blocks, 4)
         rec = np.zeros((blocks * WIRE_BLOCK, 2), np.uint32)
         rec[:n, 0] = cmds["firstInstance"]
         rec[:n, 1] = np.asarray(mesh_of_cmd, np.uint32) | (np.asarray(far_of_cmd, np.uint32) << np.uint32(31))
@@ -30,39 +35,61 @@ def encode_wire(cmds, mesh_of_cmd, far_of_cmd):
     return body
 
 
+def wire_live_mask(count, packed=False):
+    """Which words of a wire body of `count` records are specified (anchors of sub-blocks that exist, live records)."""
+    if packed:
+        blocks = (count + WIRE_PACKED_BLOCK - 1) // WIRE_PACKED_BLOCK
+        live = np.zeros((blocks, WIRE_PACKED_BLOCK_WORDS), bool)
+        live[:, :4] = True
+        slots = np.arange(blocks * WIRE_PACKED_BLOCK).reshape(blocks, WIRE_PACKED_BLOCK)
+        live[:, 4:] = slots < count
+        return live.reshape(-1)
+    blocks = (count + WIRE_BLOCK - 1) // WIRE_BLOCK
+    live = np.zeros((blocks, WIRE_BLOCK_WORDS), bool)
+    subs = np.arange(blocks * 4).reshape(blocks, 4)
+    live[:, :4] = subs * WIRE_SUB < count
+    slots = np.arange(blocks * WIRE_BLOCK).reshape(blocks, WIRE_BLOCK)
+    live[:, 4:] = np.repeat(slots < count, 2, axis=1)
+    return live.reshape(-1)
+
+
 def encode_wire_packed(cmds, mesh_of_cmd, far_of_cmd, first_instance_base, n_meshes):
     """The PACKED wire form (MIP_OUT_WIRE_PACKED), restated in numpy: one word per command, instance index in the frame
-    | mesh << index_bits | far << 31; block header {firstIndex of the block's first command, first_instance_base,
-    index_bits, 0}. Returns the body as uint32 words (whole blocks; unused slots zero)."""
+    | mesh << index_bits | far << 31, in blocks of 64; block header {firstIndex of the block's first command,
+    first_instance_base, index_bits, 0}. Returns the body as uint32 words (whole blocks; unused slots zero)."""
     n = len(cmds)
     bits = wire_index_bits(n_meshes)
-    blocks = (n + WIRE_BLOCK - 1) // WIRE_BLOCK
+    blocks = (n + WIRE_PACKED_BLOCK - 1) // WIRE_PACKED_BLOCK
     body = np.zeros(blocks * WIRE_PACKED_BLOCK_WORDS, np.uint32)
     v = body.reshape(blocks, WIRE_PACKED_BLOCK_WORDS)
     if n:
-        v[:, 0] = cmds["firstIndex"][::WIRE_BLOCK]
+        v[:, 0] = cmds["firstIndex"][::WIRE_PACKED_BLOCK]
         v[:, 1] = np.uint32(first_instance_base)
         v[:, 2] = bits
         idx = (cmds["firstInstance"] - np.uint32(first_instance_base)).astype(np.uint32)
         assert int(idx.max()) < (1 << bits), "the frame does not fit a packed record"
-        rec = np.zeros(blocks * WIRE_BLOCK, np.uint32)
+        rec = np.zeros(blocks * WIRE_PACKED_BLOCK, np.uint32)
         rec[:n] = idx | (np.asarray(mesh_of_cmd, np.uint32) << np.uint32(bits)) | (np.asarray(far_of_cmd, np.uint32) << np.uint32(31))
-        v[:, 4:] = rec.reshape(blocks, WIRE_BLOCK)
+        v[:, 4:] = rec.reshape(blocks, WIRE_PACKED_BLOCK)
     return body
 
 
 def unpack_wire(body, count):
-    """The packed body of `count` records as the 8-byte form's body (same blocks, records {firstInstance, mesh | far << 31})."""
+    """The packed body of `count` records as the 8-byte form's body (blocks of 256 records {firstInstance, mesh | far << 31},
+    four anchors per block)."""
+    pblocks = (count + WIRE_PACKED_BLOCK - 1) // WIRE_PACKED_BLOCK
+    v = np.asarray(body[: pblocks * WIRE_PACKED_BLOCK_WORDS], np.uint32).reshape(pblocks, WIRE_PACKED_BLOCK_WORDS)
     blocks = (count + WIRE_BLOCK - 1) // WIRE_BLOCK
-    v = np.asarray(body[: blocks * WIRE_PACKED_BLOCK_WORDS], np.uint32).reshape(blocks, WIRE_PACKED_BLOCK_WORDS)
     out = np.zeros((blocks, WIRE_BLOCK_WORDS), np.uint32)
-    out[:, 0] = v[:, 0]
+    anchors = np.zeros(blocks * 4, np.uint32)
+    anchors[:pblocks] = v[:, 0]
+    out[:, :4] = anchors.reshape(blocks, 4)
     r = v[:, 4:]
     bits = v[:, 2:3]
     low = r & np.uint32(0x7FFFFFFF)
-    rec = np.zeros((blocks, WIRE_BLOCK, 2), np.uint32)
-    rec[:, :, 0] = v[:, 1:2] + (low & ((np.uint32(1) << bits) - np.uint32(1)))
-    rec[:, :, 1] = (low >> bits) | (r & np.uint32(0x80000000))
+    rec = np.zeros((blocks * WIRE_BLOCK, 2), np.uint32)
+    rec[: pblocks * WIRE_PACKED_BLOCK, 0] = (v[:, 1:2] + (low & ((np.uint32(1) << bits) - np.uint32(1)))).reshape(-1)
+    rec[: pblocks * WIRE_PACKED_BLOCK, 1] = ((low >> bits) | (r & np.uint32(0x80000000))).reshape(-1)
     out[:, 4:] = rec.reshape(blocks, 2 * WIRE_BLOCK)
     return out.reshape(-1)
 
@@ -82,10 +109,11 @@ def decode_wire(body, count, meshes):
     out["instanceCount"] = 1
     out["vertexOffset"] = meshes["vertex_offset"][mesh]
     out["firstInstance"] = rec[:, 0]
-    for b in range(blocks):
-        sl = slice(b * WIRE_BLOCK, min(count, (b + 1) * WIRE_BLOCK))
+    anchors = v[:, :4].reshape(-1)
+    for q in range((count + WIRE_SUB - 1) // WIRE_SUB):
+        sl = slice(q * WIRE_SUB, min(count, (q + 1) * WIRE_SUB))
         l = lens[sl].astype(np.uint64)
-        out["firstIndex"][sl] = ((np.cumsum(l) - l + np.uint64(v[b, 0])) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        out["firstIndex"][sl] = ((np.cumsum(l) - l + np.uint64(anchors[q])) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     return out
 
 
@@ -159,7 +187,8 @@ class OraclePipeline:
 
     def merge_wire_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0, packed=False):
         lists, totals = [], []
-        fits = (stride - SHARD_HEADER_BYTES) // ((WIRE_PACKED_BLOCK_WORDS if packed else WIRE_BLOCK_WORDS) * 4) * WIRE_BLOCK
+        fits = ((stride - SHARD_HEADER_BYTES) // (WIRE_PACKED_BLOCK_WORDS * 4) * WIRE_PACKED_BLOCK if packed
+                else (stride - SHARD_HEADER_BYTES) // (WIRE_BLOCK_WORDS * 4) * WIRE_BLOCK)
         capacity = min(chunk_capacity, fits) if chunk_capacity else fits
         for k in range(n_chunks):
             h = _view(chunks_ptr + k * stride, 8, np.uint32)

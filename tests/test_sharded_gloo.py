@@ -87,10 +87,10 @@ def test_shard_ranges_cover_everything():
     assert chunk_stride_bytes(0, wire=True) == 256 and chunk_stride_bytes(1, wire=True) == 2304
     assert chunk_stride_bytes(256, wire=True) == 2304 and chunk_stride_bytes(257, wire=True) == 4352
     assert chunk_stride_bytes(336_000, wire=True) / chunk_stride_bytes(336_000) < 0.41
-    # the packed form: blocks of 1040 B; ~20 % of the 20-byte form
-    assert chunk_stride_bytes(0, wire="packed") == 256 and chunk_stride_bytes(1, wire="packed") == 1280
-    assert chunk_stride_bytes(257, wire=2) == 2304
-    assert chunk_stride_bytes(336_000, wire="packed") / chunk_stride_bytes(336_000) < 0.21
+    # the packed form: blocks of 64 records = 272 B; ~21 % of the 20-byte form
+    assert chunk_stride_bytes(0, wire="packed") == 256 and chunk_stride_bytes(1, wire="packed") == 512
+    assert chunk_stride_bytes(64, wire=2) == 512 and chunk_stride_bytes(257, wire=2) == 1536
+    assert chunk_stride_bytes(336_000, wire="packed") / chunk_stride_bytes(336_000) < 0.22
 
 
 def test_wire_form_round_trips_through_the_numpy_restatement():
@@ -98,7 +98,7 @@ def test_wire_form_round_trips_through_the_numpy_restatement():
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     import oracle
-    from cpu_pipeline import WIRE_BLOCK_WORDS, WIRE_PACKED_BLOCK_WORDS, decode_wire, encode_wire, encode_wire_packed, unpack_wire
+    from cpu_pipeline import WIRE_BLOCK_WORDS, WIRE_PACKED_BLOCK_WORDS, decode_wire, encode_wire, encode_wire_packed, unpack_wire, wire_live_mask
     from renderer_amd import scene
     from renderer_amd.pipeline import wire_index_bits
 
@@ -116,12 +116,8 @@ def test_wire_form_round_trips_through_the_numpy_restatement():
         back = decode_wire(body, len(cmds), s["meshes"])
         assert back.tobytes() == cmds.tobytes(), n
         packed = encode_wire_packed(cmds, s["mesh_id"][inst], far, 77, len(s["meshes"]))
-        assert packed.size == (len(cmds) + 255) // 256 * WIRE_PACKED_BLOCK_WORDS
-        live = np.zeros(body.size, bool)  # the unused slots of the last block are zero in one form, {base, 0} in the other
-        for b in range(body.size // WIRE_BLOCK_WORDS):
-            k = min(256, len(cmds) - 256 * b)
-            live[b * WIRE_BLOCK_WORDS: b * WIRE_BLOCK_WORDS + 1] = True
-            live[b * WIRE_BLOCK_WORDS + 4: b * WIRE_BLOCK_WORDS + 4 + 2 * k] = True
+        assert packed.size == (len(cmds) + 63) // 64 * WIRE_PACKED_BLOCK_WORDS
+        live = wire_live_mask(len(cmds))  # the unused slots of the last block are zero in one form, {base, 0} in the other
         assert np.array_equal(unpack_wire(packed, len(cmds))[live], body[live]), n
         assert decode_wire(unpack_wire(packed, len(cmds)), len(cmds), s["meshes"]).tobytes() == cmds.tobytes(), n
 
@@ -222,13 +218,14 @@ def test_wire_fixture_pins_the_byte_layout():
     inst = (cmds["firstInstance"] - np.uint32(g["first_instance_base"])).astype(np.int64)
     far = np.array([oracle.pick_lod(2, g["cam_pos"], g["pos"][i]) for i in inst], np.uint32)
     assert np.array_equal(encode_wire(cmds, g["mesh_id"][inst], far), w["body"])
-    # the layout itself: block b starts at word 516 b; word 0 = firstIndex of its first command; records from word 4
+    # the layout itself: block b starts at word 516 b; header word q = firstIndex of the block's record 64 q; records from word 4
     assert int(w["body"][0]) == int(cmds["firstIndex"][0]) and int(w["body"][516]) == int(cmds["firstIndex"][256])
+    assert [int(x) for x in w["body"][516:520]] == [int(cmds["firstIndex"][256 + 64 * q]) for q in range(4)]
     assert int(w["body"][4]) == int(cmds["firstInstance"][0]) and int(w["body"][516 + 4 + 2]) == int(cmds["firstInstance"][257])
-    # the packed form of the same list: blocks of 260 words, header {firstIndex, first_instance_base, index bits (64 meshes: 25), 0},
-    # one word per record: instance index | mesh << 25 | far << 31
+    # the packed form of the same list: blocks of 64 records = 68 words, header {firstIndex, first_instance_base, index bits (64
+    # meshes: 25), 0}, one word per record: instance index | mesh << 25 | far << 31
     pk = w["body_packed"]
-    assert pk.size == 5 * 260 and np.array_equal(encode_wire_packed(cmds, g["mesh_id"][inst], far, g["first_instance_base"], len(g["meshes"])), pk)
-    assert [int(x) for x in pk[260:264]] == [int(cmds["firstIndex"][256]), int(g["first_instance_base"]), 25, 0]
-    assert int(pk[260 + 4 + 1]) == int(inst[257]) | (int(g["mesh_id"][inst[257]]) << 25) | (int(far[257]) << 31)
+    assert pk.size == 18 * 68 and np.array_equal(encode_wire_packed(cmds, g["mesh_id"][inst], far, g["first_instance_base"], len(g["meshes"])), pk)
+    assert [int(x) for x in pk[4 * 68:4 * 68 + 4]] == [int(cmds["firstIndex"][256]), int(g["first_instance_base"]), 25, 0]
+    assert int(pk[4 * 68 + 4 + 1]) == int(inst[257]) | (int(g["mesh_id"][inst[257]]) << 25) | (int(far[257]) << 31)
     assert decode_wire(unpack_wire(pk, len(cmds)), len(cmds), g["meshes"]).tobytes() == cmds.tobytes()

@@ -48,6 +48,27 @@ for _ in range(20):
     merge(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap)
 t = p.timings()
 ms = t["total_merge_ms"] / t["merges"]
-per_cmd = (4.0625 + 20) if WIRE == "packed" else ((8.0625 + 20) if WIRE else 40)
-print(f"{'packed wire' if WIRE == 'packed' else ('wire' if WIRE else '20-byte')} form, {R} chunks x {count} cmds: merge {ms*1e3:.1f} us, {R*count*per_cmd/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
+per_cmd = (4.25 + 20) if WIRE == "packed" else ((8.0625 + 20) if WIRE else 40)
+name = "packed wire" if WIRE == "packed" else ("wire" if WIRE else "20-byte")
+print(f"{name} form, {R} chunks x {count} cmds: LONE launches (hipEvent pair around each, GPU idle in between) {ms*1e3:.1f} us, {R*count*per_cmd/ms/1e6:.0f} GB/s (read+write); total {int(oc[0].item())}")
+# back to back on one stream, as the step issues it (behind the all-gather, the GPU already busy): median of 20 samples of 20 merges
+import ctypes
+st = torch.cuda.Stream()
+q = renderer_amd.InstancePipeline(n, len(s["meshes"]), stream=st.cuda_stream)
+q.set_mesh_table(s["meshes"])
+samples = []
+with torch.cuda.stream(st):
+    for _ in range(20):
+        merge2 = (lambda *a, **kw: q.merge_wire_lists(*a, packed=(WIRE == "packed"), **kw)) if WIRE else q.merge_draw_lists
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(20):
+            merge2(recv.data_ptr(), R, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap, async_=True)
+        e1.record(st)
+        e1.synchronize()
+        samples.append(e0.elapsed_time(e1) / 20 * 1e3)
+    q.wait()
+us = float(np.median(samples))
+print(f"{name} form, {R} chunks x {count} cmds: BACK TO BACK {us:.1f} us per merge (min {min(samples):.1f}), {R*count*per_cmd/us/1e3:.0f} GB/s (read+write) = {R*count*per_cmd/us/1e3/8000:.3f} of 8 TB/s")
+q.close()
 p.close()
