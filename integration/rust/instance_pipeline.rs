@@ -118,6 +118,9 @@ pub(crate) struct ZeroCopyTargets {
 unsafe impl Send for ZeroCopyTargets {}
 unsafe impl Sync for ZeroCopyTargets {}
 
+/// MipConfig.frames_in_flight of the context = the renderer's swapchain image count (DoubleBuffered<..>, src/renderer.rs:1225-1249)
+const FRAMES_IN_FLIGHT: u32 = 2;
+
 pub(crate) fn instance_pipeline_zero_copy(pipeline: Res<InstancePipeline>, targets: Res<ZeroCopyTargets>, camera: Res<Camera>,
                                           frame_number: Res<crate::renderer::FrameNumber>) {
     let ctx = pipeline.ctx.0;
@@ -148,5 +151,17 @@ pub(crate) fn instance_pipeline_zero_copy(pipeline: Res<InstancePipeline>, targe
         // ... and ComputeCull's semaphore reaches this frame's value when its kernels have: the graphics submit waits on it
         assert_eq!(mip_sys::mip_signal_external(ctx, targets.cull_done, n), mip_sys::MIP_OK);
     }
-    // nothing is copied and nothing waits on the host; cull_pass keeps its frame-graph node only to carry the semaphore
+    // Nothing is copied and nothing waits on the host PER FRAME; cull_pass keeps its frame-graph node only to carry the semaphore.
+    // The library's deferred errors (an external semaphore that expired, MIP_ERR_CAPACITY of the per-triangle stage) surface in
+    // mip_wait, so a semaphore-ordered loop still calls it at a bounded cadence: every FRAMES_IN_FLIGHT-th frame, i.e. behind a
+    // frame whose consumer semaphore (`consumers_done`, value n - 1 above) this thread has already seen pass — the wait then
+    // returns at once. (Frames cannot stall or time out on the device any more: MipTimings.prefix_helps only counts how often a
+    // tile had to compute a predecessor's aggregate itself.)
+    if n % FRAMES_IN_FLIGHT as u64 == 0 {
+        let rc = unsafe { mip_sys::mip_wait(ctx) };
+        if rc != mip_sys::MIP_OK {
+            let msg = unsafe { std::ffi::CStr::from_ptr(mip_sys::mip_last_error(ctx)) };
+            panic!("instance pipeline: {} ({})", msg.to_string_lossy(), rc);  // panic = "abort" in both profiles (Cargo.toml:133,138)
+        }
+    }
 }

@@ -720,6 +720,7 @@ int32_t mip_wait(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
+  if (int32_t rc = interop_drain(ctx)) return rc;  // the signals of external semaphores behind the drained frames have gone out
   ctx->pending_async = false;
   int32_t rc = check_device_error(ctx);
   ctx->sharded_pending = 0;

@@ -10,10 +10,17 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace mip_host {
 
+void stop_semaphore_workers(MipContext* ctx);
+
 void interop_release(MipContext* ctx) {
+  stop_semaphore_workers(ctx);
   for (auto& e : ctx->externals) (void)hipDestroyExternalMemory(e.mem);  // unmaps the buffer as well
   ctx->externals.clear();
   for (auto* e : ctx->semaphores) {
@@ -23,6 +30,7 @@ void interop_release(MipContext* ctx) {
       d.handle = e->drm_handle;
       (void)ioctl(ctx->drm_fd, DRM_IOCTL_SYNCOBJ_DESTROY, &d);
     }
+    if (e->words) (void)hipHostFree(e->words);
     delete e;
   }
   ctx->semaphores.clear();
@@ -102,52 +110,58 @@ static int drm_ioctl(int fd, unsigned long request, void* arg) {
   return rc;
 }
 
-static void semaphore_host_fn(void* p) {
-  SemaphoreOp* op = static_cast<SemaphoreOp*>(p);
-  uint32_t handle = op->handle;
-  uint64_t point = op->value;
+// One wait or signal on the kernel object; false when the ioctl failed or the 10 s expired.
+static bool perform_semaphore_op(int drm_fd, uint32_t handle_in, uint32_t kind, uint64_t point_in, bool signal) {
+  uint32_t handle = handle_in;
+  uint64_t point = point_in;
   int rc = 0;
-  if (op->signal) {
-    if (op->kind == MIP_SEMAPHORE_TIMELINE) {
+  if (signal) {
+    if (kind == MIP_SEMAPHORE_TIMELINE) {
       drm_syncobj_timeline_array a{};
       a.handles = (uintptr_t)&handle;
       a.points = (uintptr_t)&point;
       a.count_handles = 1;
-      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL, &a);
+      rc = drm_ioctl(drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_SIGNAL, &a);
     } else {
       drm_syncobj_array a{};
       a.handles = (uintptr_t)&handle;
       a.count_handles = 1;
-      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_SIGNAL, &a);
+      rc = drm_ioctl(drm_fd, DRM_IOCTL_SYNCOBJ_SIGNAL, &a);
     }
   } else {
     timespec now;
     clock_gettime(CLOCK_MONOTONIC, &now);
     const int64_t deadline = (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec + kSemaphoreWaitNs;
-    if (op->kind == MIP_SEMAPHORE_TIMELINE) {
+    if (kind == MIP_SEMAPHORE_TIMELINE) {
       drm_syncobj_timeline_wait w{};
       w.handles = (uintptr_t)&handle;
       w.points = (uintptr_t)&point;
       w.timeout_nsec = deadline;
       w.count_handles = 1;
       w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;  // the point may not have been submitted yet
-      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_WAIT, &w);
+      rc = drm_ioctl(drm_fd, DRM_IOCTL_SYNCOBJ_TIMELINE_WAIT, &w);
     } else {
       drm_syncobj_wait w{};
       w.handles = (uintptr_t)&handle;
       w.timeout_nsec = deadline;
       w.count_handles = 1;
       w.flags = DRM_SYNCOBJ_WAIT_FLAGS_WAIT_FOR_SUBMIT;
-      rc = drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_WAIT, &w);
+      rc = drm_ioctl(drm_fd, DRM_IOCTL_SYNCOBJ_WAIT, &w);
       if (rc == 0) {  // a binary semaphore is consumed by its wait
         drm_syncobj_array a{};
         a.handles = (uintptr_t)&handle;
         a.count_handles = 1;
-        (void)drm_ioctl(op->drm_fd, DRM_IOCTL_SYNCOBJ_RESET, &a);
+        (void)drm_ioctl(drm_fd, DRM_IOCTL_SYNCOBJ_RESET, &a);
       }
     }
   }
-  if (rc != 0) *op->error_word = mip::kErrSemaphore;
+  return rc == 0;
+}
+
+// (fall-back path: runtimes without hipStreamWaitValue64, or MIP_TUNE_SEMAPHORE_HOST_FUNCTIONS=1 for an A/B)
+static void semaphore_host_fn(void* p) {
+  SemaphoreOp* op = static_cast<SemaphoreOp*>(p);
+  if (!perform_semaphore_op(op->drm_fd, op->handle, op->kind, op->value, op->signal)) *op->error_word = mip::kErrSemaphore;
   delete op;
 }
 
@@ -161,6 +175,147 @@ static int32_t enqueue_semaphore_op(MipContext* ctx, MipContext::ExternalSemapho
   }
   return MIP_OK;
 }
+
+}  // extern "C"
+
+// ---- DRM sync object path WITHOUT host functions on the stream -----------------------------------------------------------
+// Measured (tools/micro/semaphore_frames.cpp, profiles/r04_external_semaphore_handover.txt): with the wait and the signal of a
+// frame as two hipLaunchHostFunc calls, a 1 M-instance frame that takes 17.7 us bare takes 110 us (80 us in a ping-pong
+// with a consumer thread): ~45 us per host function. Instead:
+//   wait    the stream holds a hipStreamWaitValue64 on a pinned word (the hardware waits, no runtime thread involved); a
+//           WAITER thread of the library blocks in the DRM wait ioctl and stores the sequence number the stream is waiting for;
+//   signal  the stream stores a sequence number into a second pinned word (hipStreamWriteValue64) behind the frame; a
+//           SIGNALLER thread polls that word and performs the DRM signal ioctl.
+// Two threads, because a wait that blocks (the consumer of frame k has not finished) must not keep the signal of frame k
+// from going out — the consumer is waiting for exactly that. The threads sleep on a condition variable while nothing is
+// queued; the signaller spins only while a frame whose signal is queued is on the device.
+struct MipContext::SemaphoreWorkers {
+  struct Request {
+    MipContext::ExternalSemaphore* sem;
+    uint64_t value;
+    unsigned long long seq;
+  };
+  std::mutex m;
+  std::condition_variable wake_waiter, wake_signaller, idle;
+  std::deque<Request> waits, signals;
+  bool waiter_busy = false, signaller_busy = false, stop = false;
+  std::thread waiter, signaller;
+  int drm_fd = -1;
+  volatile uint32_t* error_word = nullptr;
+};
+
+namespace mip_host {
+
+static void waiter_main(MipContext::SemaphoreWorkers* w) {
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    w->wake_waiter.wait(lk, [&] { return w->stop || !w->waits.empty(); });
+    if (w->stop) return;
+    const auto rq = w->waits.front();
+    w->waits.pop_front();
+    w->waiter_busy = true;
+    lk.unlock();
+    if (!perform_semaphore_op(w->drm_fd, rq.sem->drm_handle, rq.sem->kind, rq.value, false)) *w->error_word = mip::kErrSemaphore;
+    // granted (or expired: reported, and the frame behind it runs anyway, as the header says): release the stream
+    __atomic_store_n(&rq.sem->words[0], rq.seq, __ATOMIC_RELEASE);
+    lk.lock();
+    w->waiter_busy = false;
+    w->idle.notify_all();
+  }
+}
+
+static void signaller_main(MipContext::SemaphoreWorkers* w) {
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    w->wake_signaller.wait(lk, [&] { return w->stop || !w->signals.empty(); });
+    if (w->stop) return;
+    const auto rq = w->signals.front();
+    w->signals.pop_front();
+    w->signaller_busy = true;
+    lk.unlock();
+    // the stream stores rq.seq when everything in front of the signal has finished
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    uint32_t polls = 0;
+    bool reached = true;
+    while (__atomic_load_n(&rq.sem->words[1], __ATOMIC_ACQUIRE) < rq.seq) {
+      if (__atomic_load_n(&w->stop, __ATOMIC_RELAXED)) { reached = false; break; }
+      if (++polls < 4096u) continue;  // a frame is tens of microseconds: spin that long ...
+      timespec now;
+      clock_gettime(CLOCK_MONOTONIC, &now);
+      if ((now.tv_sec - t0.tv_sec) * 1000000000ll + (now.tv_nsec - t0.tv_nsec) > 2 * kSemaphoreWaitNs) { reached = false; break; }
+      timespec nap{0, 20000};         // ... then look every 20 us
+      nanosleep(&nap, nullptr);
+    }
+    if (!reached || !perform_semaphore_op(w->drm_fd, rq.sem->drm_handle, rq.sem->kind, rq.value, true)) *w->error_word = mip::kErrSemaphore;
+    lk.lock();
+    w->signaller_busy = false;
+    w->idle.notify_all();
+  }
+}
+
+void stop_semaphore_workers(MipContext* ctx) {
+  MipContext::SemaphoreWorkers* w = ctx->semaphore_workers;
+  if (!w) return;
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->stop = true;
+  }
+  w->wake_waiter.notify_all();
+  w->wake_signaller.notify_all();
+  if (w->waiter.joinable()) w->waiter.join();
+  if (w->signaller.joinable()) w->signaller.join();
+  delete w;
+  ctx->semaphore_workers = nullptr;
+}
+
+// Every queued wait has been granted and every queued signal performed (the streams have drained: mip_wait).
+int32_t interop_drain(MipContext* ctx) {
+  MipContext::SemaphoreWorkers* w = ctx->semaphore_workers;
+  if (!w) return MIP_OK;
+  std::unique_lock<std::mutex> lk(w->m);
+  const bool ok = w->idle.wait_for(lk, std::chrono::seconds(30), [&] { return w->waits.empty() && w->signals.empty() && !w->waiter_busy && !w->signaller_busy; });
+  return ok ? MIP_OK : fail(ctx, MIP_ERR_TIMEOUT, "the external-semaphore helper threads did not drain");
+}
+
+}  // namespace mip_host
+
+static bool stream_values_usable(MipContext* ctx) {
+  static int usable = -1;
+  if (usable < 0) {
+    int can = 0;
+    usable = (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can) ? 1 : 0;
+    (void)hipGetLastError();
+    if (std::getenv("MIP_TUNE_SEMAPHORE_HOST_FUNCTIONS")) usable = 0;  // A/B: the host-function path of round 3
+  }
+  return usable == 1;
+}
+
+// The DRM path of mip_wait_external / mip_signal_external.
+static int32_t enqueue_drm_semaphore(MipContext* ctx, MipContext::ExternalSemaphore* s, uint64_t value, bool signal, hipStream_t stream) {
+  if (!s->words || !stream_values_usable(ctx)) return enqueue_semaphore_op(ctx, s, value, signal, stream);
+  MipContext::SemaphoreWorkers* w = ctx->semaphore_workers;
+  if (!w) {
+    w = new (std::nothrow) MipContext::SemaphoreWorkers();
+    if (!w) return fail(ctx, MIP_ERR_OUT_OF_MEMORY, "out of host memory");
+    w->drm_fd = ctx->drm_fd;
+    w->error_word = ctx->h_error + 5;
+    w->waiter = std::thread(waiter_main, w);
+    w->signaller = std::thread(signaller_main, w);
+    ctx->semaphore_workers = w;
+  }
+  const unsigned long long seq = signal ? ++s->signal_seq : ++s->wait_seq;
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    (signal ? w->signals : w->waits).push_back({s, value, seq});
+  }
+  (signal ? w->wake_signaller : w->wake_waiter).notify_one();
+  if (signal) MIP_HIP(ctx, hipStreamWriteValue64(stream, &s->words[1], seq, 0));
+  else MIP_HIP(ctx, hipStreamWaitValue64(stream, &s->words[0], seq, hipStreamWaitValueGte, ~0ull));
+  return MIP_OK;
+}
+
+extern "C" {
 
 int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t kind, MipExternalSemaphore** out_semaphore) {
   if (out_semaphore) *out_semaphore = nullptr;
@@ -195,9 +350,19 @@ int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t k
     drm_handle = h.handle;
     close(fd);  // imported: the fd belonged to the library from here on (the sync object lives on through the handle)
   }
-  auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind, drm_handle};
+  unsigned long long* words = nullptr;
+  if (drm_handle && stream_values_usable(ctx)) {  // two pinned, device-visible sequence words (stream-value hand-over)
+    if (hipHostMalloc((void**)&words, 64, hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      words = nullptr;  // fall back to host functions for this semaphore
+    } else {
+      std::memset(words, 0, 64);
+    }
+  }
+  auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind, drm_handle, words, 0ull, 0ull};
   if (!entry) {
     if (sem) (void)hipDestroyExternalSemaphore(sem);
+    if (words) (void)hipHostFree(words);
     return fail(ctx, MIP_ERR_OUT_OF_MEMORY, "out of host memory");
   }
   ctx->semaphores.push_back(entry);
@@ -223,7 +388,7 @@ int32_t mip_wait_external(MipContext* ctx, MipExternalSemaphore* semaphore, uint
     hipExternalSemaphoreWaitParams p{};
     p.params.fence.value = value;
     MIP_HIP(ctx, hipWaitExternalSemaphoresAsync(&s->sem, &p, 1, stream));
-  } else if (int32_t rc = enqueue_semaphore_op(ctx, s, value, false, stream)) {
+  } else if (int32_t rc = enqueue_drm_semaphore(ctx, s, value, false, stream)) {
     return rc;
   }
   ctx->pending_async = true;
@@ -241,7 +406,7 @@ int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, ui
     hipExternalSemaphoreSignalParams p{};
     p.params.fence.value = value;
     MIP_HIP(ctx, hipSignalExternalSemaphoresAsync(&s->sem, &p, 1, stream));
-  } else if (int32_t rc = enqueue_semaphore_op(ctx, s, value, true, stream)) {
+  } else if (int32_t rc = enqueue_drm_semaphore(ctx, s, value, true, stream)) {
     return rc;
   }
   ctx->pending_async = true;
@@ -255,7 +420,9 @@ int32_t mip_release_external_semaphore(MipContext* ctx, MipExternalSemaphore* se
   if (!s) return fail(ctx, MIP_ERR_INVALID_ARGUMENT, "not a semaphore returned by mip_import_external_semaphore_fd");
   if (int32_t rc = bind_device(ctx)) return rc;
   if (int32_t rc = sync_all(ctx)) return rc;
+  if (int32_t rc = interop_drain(ctx)) return rc;
   if (s->sem) MIP_HIP(ctx, hipDestroyExternalSemaphore(s->sem));
+  if (s->words) (void)hipHostFree(s->words);
   if (s->drm_handle) {
     drm_syncobj_destroy d{};
     d.handle = s->drm_handle;

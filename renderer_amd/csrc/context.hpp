@@ -153,8 +153,19 @@ struct MipContext {
   // execute on the device), or — when the runtime refuses the handle type, as ROCm 7.2 on Linux does — the kernel
   // object itself: the fd of an exported Vulkan semaphore is a DRM sync object on amdgpu, imported on a render node
   // and waited for / signalled by host functions enqueued on the frame's stream (hipLaunchHostFunc).
-  struct ExternalSemaphore { hipExternalSemaphore_t sem; uint32_t kind; uint32_t drm_handle; };
+  struct ExternalSemaphore {
+    hipExternalSemaphore_t sem;
+    uint32_t kind;
+    uint32_t drm_handle;
+    // DRM path, stream-value hand-over (api_interop.hip): two pinned, device-visible sequence words —
+    // [0] waits granted by the waiter thread (the stream holds a hipStreamWaitValue64 on it),
+    // [1] signals reached by the stream (hipStreamWriteValue64; the signaller thread polls it) — and the sequence numbers issued so far
+    unsigned long long* words;
+    unsigned long long wait_seq, signal_seq;
+  };
   std::vector<ExternalSemaphore*> semaphores;
+  struct SemaphoreWorkers;             // the two helper threads and their queues (api_interop.hip); created with the first DRM-path semaphore
+  SemaphoreWorkers* semaphore_workers = nullptr;
   int drm_fd = -1;  // render node, opened on first use
   uint32_t last_slot = 0;  // slot of the frame issued last (mip_signal_external goes behind it)
   char err[512] = {0};
@@ -191,6 +202,7 @@ void drop_graphs(MipContext* ctx);                    // api_frame.hip
 int32_t repair_sharded_overflow(MipContext* ctx);     // api_sharded.hip
 void comm_release(MipContext* ctx);                   // api_sharded.hip: communicator + buffers, for mip_destroy
 void interop_release(MipContext* ctx);                // api_interop.hip: imported memory and semaphores, for mip_destroy
+int32_t interop_drain(MipContext* ctx);                // api_interop.hip: every queued signal of an external semaphore has been performed (mip_wait)
 int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out, bool skinned, void* palette);  // api_frame.hip
 
 }  // namespace mip_host

@@ -142,19 +142,32 @@ class DrawListExchange:
         if self._in_flight:
             self._check_stream("complete")  # a repair issues an all-gather: it must land on the pipeline's stream
         in_flight, self._in_flight = self._in_flight, 0
+        err = None
         try:
             self.pipe.wait()
-            return False
         except MipError as e:
-            if e.code != MIP_ERR_CAPACITY:
-                raise
-            if in_flight != 1:
-                raise MipError(e.code, "a tightened chunk overflowed with several frames in flight: the overflowing "
-                                       "frame's list has been overwritten; call complete() after every frame") from e
+            err = e
+        if err is None:
+            return False
+        # Whether to repair is decided from data EVERY rank holds — the gathered headers — never from which error code this
+        # rank happened to get: the merge kernel raises the overflow on every rank alike, but a rank with a second, local
+        # error (a corrupt record, an external semaphore that expired) is handed THAT code by mip_wait, and a rank that then
+        # skipped the repair's all-gather would leave its peers blocked in it for good (round-3 advisor finding).
+        overflow = False
+        if in_flight:
+            counts, _ = self.counts()
+            overflow = int(counts.max()) > self.capacity
+        if not overflow:
+            raise err
+        if in_flight != 1:
+            raise MipError(MIP_ERR_CAPACITY, "a tightened chunk overflowed with several frames in flight: the overflowing "
+                                             "frame's list has been overwritten; call complete() after every frame") from err
         self.set_capacity(self.n_max)
         self._gather_and_merge()
         self.pipe.wait()
         self.retries += 1
+        if err.code != MIP_ERR_CAPACITY:
+            raise err  # this rank's own error, reported AFTER it has taken part in the collective repair
         return True
 
     # -- host-side views (synchronising) --

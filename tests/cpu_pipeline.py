@@ -160,11 +160,16 @@ class OraclePipeline:
                 _view(draw_index_total, 4, np.uint32)[0] = r["draw_index_total"]
 
     def wait(self):
-        """As mip_wait: reports a deferred MIP_ERR_CAPACITY of an (async) merge."""
+        """As mip_wait: reports a deferred MIP_ERR_CAPACITY of an (async) merge — or, when the test has planted one
+        (`other_error_once`), ANOTHER error code that mip_wait ranks above the overflow (a corrupt record: MIP_ERR_DEVICE)."""
         if getattr(self, "_overflow", False):
             self._overflow = False
             from renderer_amd._lib import MipError
 
+            code = getattr(self, "other_error_once", None)
+            if code is not None:
+                self.other_error_once = None
+                raise MipError(code, "a local error that outranks the overflow in mip_wait")
             raise MipError(-4, "a shard's draw list is longer than the exchanged chunk holds; merged list truncated")
 
     def merge_draw_lists(self, chunks_ptr, n_chunks, stride, out_cmds_ptr, out_count_ptr, async_=False, chunk_capacity=0):

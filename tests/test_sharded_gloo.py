@@ -173,6 +173,24 @@ def _worker_overflow(rank, world, init_file, n_global, out_dir):
         ex.step(frame_a)
         check(ex, want_a, "A again")
         assert ex.retries == 1
+        # One rank's mip_wait reports ANOTHER error for the overflowing frame (a local error outranks the overflow there):
+        # that rank must still take part in the collective repair — decided from the gathered headers, which every rank
+        # holds — and report its own error afterwards; nobody hangs, everybody ends with the complete list.
+        from renderer_amd._lib import MipError
+        ex.tighten()
+        ex.step(frame_a)
+        check(ex, want_a, "A, tightened again")
+        if rank == world - 1:
+            ex.pipe.other_error_once = -5
+        ex.step(frame_b)
+        if rank == world - 1:
+            with pytest.raises(MipError) as e:
+                ex.complete()
+            assert e.value.code == -5
+        else:
+            assert ex.complete() is True
+        assert ex.retries == 2 and ex.capacity == ex.n_max
+        check(ex, want_b, "B, repaired by every rank although one had a different error")
 
         # the same with two frames in flight (two exchanges issued round-robin)
         px = PipelinedExchange(lambda stream: OraclePipeline(shard), n_local, world, rank, torch.device("cpu"),
