@@ -391,6 +391,25 @@ def views_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, str
     return row
 
 
+def skinned_pmc(n, joints):
+    """HBM bytes per skinned frame (skinning kernel + frame kernel) from the committed PMC passes (tools/pmc_skin.sh), if they were
+    taken from these sources of skinning_kernel.hpp and instance_kernel.hpp."""
+    import glob
+
+    h = hashlib.sha256()
+    for f in ("skinning_kernel.hpp", "instance_kernel.hpp"):
+        h.update(open(os.path.join(ROOT, "renderer_amd", "csrc", f), "rb").read())
+    sha = h.hexdigest()[:16]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*skinned*pmc_summary.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get("instances") == n and doc.get("joints") == joints and doc.get("source_sha") == sha:
+            return doc, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_rank):
     """BASELINE config 5 (extension, no reference semantics): 256 k instances of a 19-joint figure, each
     with its own pose: palette + skinned bounds kernel, then the instance kernel."""
@@ -419,14 +438,17 @@ def skinned_leg(torch, renderer_amd, scene, make_frame, s_unused, device, local_
     p.close()
     nbytes = n * (36 + j * 40 + j * 64 + 1) + n * (36 + 64 + 0.125 + 1) + count * 20
     skin_bytes = n * (j * 40 + j * 64 + 32)  # the skinning kernel alone: poses in, palette + posed box out
+    pmc_doc, pmc_src = skinned_pmc(n, j)
     return {
         "instances": n, "joints": j, "ms_per_frame": dt * 1e3, "instances_per_s": n / dt, "emitted_fraction": count / n,
         "algorithmic_GBps": nbytes / dt / 1e9,
         "roofline": {"bound": "hbm", "kernel": "mip_skinned_bounds_kernel + mip_instance_pipeline_kernel (one frame)", "achieved": nbytes / dt / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+                     "traffic": pmc_doc["hbm_bytes_per_frame"] if pmc_doc else None, "traffic_source": pmc_src,
+                     "per_kernel": pmc_doc.get("per_kernel") if pmc_doc else None,
                      "algorithmic_bytes_per_frame": nbytes, "skinning_kernel_bytes": skin_bytes,
-                     "note": "wall clock per frame over 50 back-to-back frames (two kernels per frame); per-kernel durations and the PMC "
-                             "traffic of the skinning kernel are in profiles/r03_skinned_*"},
+                     "note": "wall clock per frame over 50 back-to-back frames (two kernels per frame); traffic = 2 * FETCH_SIZE + WRITE_SIZE of BOTH "
+                             "kernels of a frame from the committed PMC passes of these kernel sources (tools/pmc_skin.sh), null when the sources have changed since"},
         "note": "per instance: 19 x (40 B pose read + 64 B palette written) in the skinning kernel, then the instance kernel's "
                 "100 B + 20 B per command; the reference has no skinning: parity is against this repository's oracle only",
     }
@@ -751,19 +773,83 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
         torch, renderer_amd, make_frame, scene.make_scene(3, all_visible=True), device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES)))
     guarded("mixed_10m_one_gpu_serialized", lambda: leg_summary(serialized_leg(
         torch, renderer_amd, make_frame, scene.make_scene(4), device, local_rank, stream, 5, 5, 20)))
-    # the mode for a GPU shared with other spin-waiting compute (MIP_CFG_ORDERED_TILES: no reliance on dispatch order; also what a
-    # context runs in after a stalled frame): wait-free launches instead of the one-pass kernel
+    # Since ABI 4 EVERY launch is independent of the order workgroups start in (a tile whose predecessor has not published computes
+    # that aggregate itself): there is no separate "ordered tiles" mode any more. The two keys round 3 reported for it are kept, and
+    # measure the one kernel there is, on a context created with the (now ignored) flag — so they can be read against round 3's
+    # 25.45 / 7.55 us and against the default legs above.
     guarded("mixed_1m_ordered_tiles_serialized", lambda: dict(leg_summary(serialized_leg(
         torch, renderer_amd, make_frame, s3, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)),
-        note="MIP_CFG_ORDERED_TILES: frame kernel without commands + commands from the visibility bitmap (DESIGN.md section 14.8)"))
-    guarded("damaged_helmet_100k_ordered_tiles_serialized", lambda: leg_summary(serialized_leg(
-        torch, renderer_amd, make_frame, s2, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)))
+        note="MIP_CFG_ORDERED_TILES is accepted and ignored: this is the default kernel, which no longer depends on dispatch order "
+             "(decoupled look-back with a fallback; round 3: three wait-free launches, 25.45 us)"))
+    guarded("damaged_helmet_100k_ordered_tiles_serialized", lambda: dict(leg_summary(serialized_leg(
+        torch, renderer_amd, make_frame, s2, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)),
+        note="as above (round 3: two launches, 7.55 us)"))
+    guarded("zero_copy_semaphore_frame", lambda: semaphore_leg())
+    guarded("shard_merge_8x336k", lambda: merge_leg(torch, renderer_amd, scene, make_frame, device, local_rank, stream))
     # next-tier rows (not the headline)
     guarded("triangle_cull_100k", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, not args.no_cpu_baseline))
     guarded("triangle_cull_100k_strips", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, False, ordering="strips"))
     guarded("light_draw_lists", lambda: light_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank))
     guarded("culled_views_x4", lambda: views_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank, stream))
     guarded("skinned_256k", lambda: skinned_leg(torch, renderer_amd, scene, make_frame, None, device, local_rank))
+
+
+def semaphore_leg():
+    """Row f-2: what ordering a frame against a Vulkan queue by exported timeline semaphores costs per frame. Runs
+    renderer_amd/lib/mip_semaphore_bench (tools/micro/semaphore_frames.cpp: frames issued from compiled code against two kernel
+    DRM timeline sync objects, what vkGetSemaphoreFdKHR exports on amdgpu) as a child process, for 1 M and 100 k instances."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "renderer_amd", "lib", "mip_semaphore_bench")
+    if not os.path.exists(exe):
+        return {"error": "renderer_amd/lib/mip_semaphore_bench has not been built (make -C renderer_amd/host)"}
+    rows = {}
+    for n in (1_000_000, 100_000):
+        out = subprocess.run([exe, str(n), "2000"], capture_output=True, text=True, timeout=120)
+        line = [l for l in out.stdout.split("\n") if l.startswith("{")]
+        rows[f"{n}"] = json.loads(line[-1]) if out.returncode == 0 and line else {"error": (out.stderr or out.stdout)[-400:]}
+    rows["note"] = ("microseconds per frame, wall clock over 2 000 frames from compiled code: bare = mip_run(ASYNC) back to back; free_running = "
+                    "mip_wait_external -> mip_run -> mip_signal_external per frame with the consumer timeline already ahead (frames in flight: "
+                    "the hand-over's own cost); ping_pong = every frame waits for a consumer THREAD that has seen the previous frame's signal "
+                    "(two kernel wake-ups per frame). profiles/r04_external_semaphore_handover.txt has round 3's host-function path beside it")
+    return rows
+
+
+def merge_leg(torch, renderer_amd, scene, make_frame, device, local_rank, stream):
+    """Row e, the shard merge alone, on the 8-rank shape of BASELINE configs[3] (8 chunks of a 1.25 M-instance shard's list): back to
+    back on one stream, HIP events, both wire forms; bytes = wire bytes read + 20 B written per command."""
+    from renderer_amd.pipeline import SHARD_HEADER_BYTES
+    from renderer_amd.sharded import chunk_stride_bytes
+
+    n, ranks, cap = 1_250_000, 8, 360_000
+    s = scene.make_scene(4, n=n)
+    p = make_pipe(renderer_amd, s, local_rank, stream=stream)
+    rows = {}
+    for form, name, per_cmd in (("packed", "packed_wire", 4.25 + 20), (True, "wire_8_byte", 8.0625 + 20)):
+        stride = chunk_stride_bytes(cap, wire=form)
+        recv = torch.zeros(ranks * stride // 4, dtype=torch.int32, device=device)
+        merged = torch.zeros((ranks * cap, 5), dtype=torch.int32, device=device)
+        oc = torch.zeros(2, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        for k in range(ranks):
+            base = recv.data_ptr() + k * stride
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_instance_base=k * n), draw_cmds=base + SHARD_HEADER_BYTES,
+                         draw_count=base, draw_index_total=base + 4, wire=form)
+        count = int(recv[0].item())
+
+        def step():
+            p.merge_wire_lists(recv.data_ptr(), ranks, stride, merged.data_ptr(), oc.data_ptr(), chunk_capacity=cap, packed=(form == "packed"), async_=True)
+
+        ev, _ = event_samples(torch, step, 20, 20, 20)
+        p.wait()
+        ms = float(np.median(ev))
+        nbytes = ranks * count * per_cmd
+        rows[name] = {"chunks": ranks, "commands_per_chunk": count, "ms_per_merge": ms, "algorithmic_GBps": nbytes / (ms * 1e-3) / 1e9,
+                      "frac_of_8000": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "merged_commands": int(oc[0].item()), "timing": stats(ev)}
+    p.close()
+    rows["note"] = ("mip_merge_wire_lists[_packed] alone, 20 back-to-back merges per HIP-event sample (as the step issues it: behind the "
+                    "all-gather, the GPU busy); round 3's kernel: 16.8 / 15.9 us in the kernel trace, this round's: profiles/r04_wire_merge.txt")
+    return rows
 
 
 def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, local_rank, rank, world, stream, result, extra):
@@ -783,52 +869,25 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
     # 1: 8-byte records, 0: 20-byte commands
     wire_env = os.environ.get("MIP_BENCH_WIRE", "2")
     ex = DrawListExchange(pipe, n_local, world, rank, device, wire={"0": False, "1": 1}.get(wire_env, True))
-    timeouts = [0]
-
-    def settle():
-        """complete() that survives a MIP_ERR_TIMEOUT: the context has then switched itself to ticketed tiles (the
-        dispatch-order assumption was violated — seen when several spin-waiting launches of different processes
-        shared one GPU); the frame is lost, the run goes on, and the line says so."""
-        try:
-            ex.complete()
-        except renderer_amd.MipError as e:
-            if e.code != -7:
-                raise
-            timeouts[0] += 1
-
     def timed():
         out = barrier_samples(torch, dist, lambda: ex.step(frame, outs), args.steps, args.warmup, samples, True)
-        settle()
+        ex.complete()
         return out
 
-    def timeouts_anywhere():
-        """The largest timeout count over the ranks. Every decision that changes what is issued next (repeat a frame,
-        measure again) is taken on THIS number, never on the local one: a rank that repeated a frame on its own would
-        issue one all-gather more than its peers."""
-        t = torch.tensor([timeouts[0]], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return int(t.item())
-
+    # (round 3 carried a collective "did anybody time out" protocol here: a frame kernel's bounded wait could expire when several
+    #  processes shared one GPU. No kernel waits for another workgroup any more, so a frame cannot time out; what is reported
+    #  instead is how many tile aggregates waiting tiles computed themselves — 0 on GPUs the ranks have to themselves.)
     ex.step(frame, outs)
-    settle()
+    ex.complete()
     capacity_full = ex.capacity
     ex.tighten()   # the exchanged chunk = the largest shard list of the first frame + 6 %; an overflow is repaired, not lost
     ex.step(frame, outs)
-    settle()
-    if timeouts_anywhere():  # the frames above are invalid somewhere: repeat them (that rank's context has fallen back to ordered tiles)
-        ex.set_capacity(ex.n_max)
-        ex.step(frame, outs)
-        settle()
-        ex.tighten()
+    ex.complete()
     counts, _ = ex.counts()
     samples = max(10, min(args.samples, 30))
-    before = timeouts_anywhere()
     ms = timed()
-    after = timeouts_anywhere()
-    if after != before:  # a frame of the timed loop expired (0.5 s stall inside the samples): measure again
-        ms = timed()
-        after = timeouts_anywhere()
-    any_timeouts = after
+    helps = torch.tensor([pipe.timings()["prefix_helps"]], dtype=torch.int64, device="cuda")
+    dist.all_reduce(helps, op=dist.ReduceOp.MAX)
     med = float(np.median(ms))
     result.update({
         "value": n_total / (med * 1e-3),
@@ -846,12 +905,12 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
             "chunk_bytes_per_rank": int(ex.stride),
             "chunk_format": {0: "20-byte commands",
                              1: "wire: 8-byte records {firstInstance, mesh | lod} in blocks of 256 (MIP_OUT_WIRE), expanded by the merge",
-                             2: "packed wire: 4-byte records {instance index | mesh | lod} in blocks of 256 (MIP_OUT_WIRE_PACKED), expanded by the merge"}[ex.form],
+                             2: "packed wire: 4-byte records {instance index | mesh | lod} in blocks of 64 (MIP_OUT_WIRE_PACKED, 4.25 B per command), expanded by the merge"}[ex.form],
             "chunk_bytes_per_rank_as_20_byte_commands": int((32 + ex.capacity * 20 + 255) // 256 * 256),
             "chunk_capacity_commands": int(ex.capacity),
             "chunk_capacity_untightened": int(capacity_full),
             "n_ranks_seen": int(dist.get_world_size()),
-            "ordered_tiles_fallback": bool(any_timeouts),
+            "prefix_helps_max_over_ranks": int(helps.item()),
             "frames_in_flight": 1,
             "host_loop": "python: kernel -> all_gather_into_tensor -> merge per step on one stream",
             "outputs": "per rank: its shard's model[] + bitmap; every rank: the merged global draw list",
@@ -877,10 +936,15 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
         }
         local_v = float(counts[rank]) / max(n_local, 1)
         kb = n_local * algorithmic_bytes_per_instance(local_v)
+        pmc3, stale3 = pmc_traffic(3, 1_000_000)
         kms = float(np.median(k_ms))
         result["roofline"] = {
             "bound": "hbm", "kernel": "mip_instance_pipeline_kernel", "achieved": kb / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # (the committed PMC pass is BASELINE configs[2]: 1 M instances, emitted fraction 0.268553 = 105.50 MB algorithmic)
+            "traffic": (pmc3["hbm_bytes_per_launch"] / (1_000_000 * algorithmic_bytes_per_instance(0.268553)) * kb) if pmc3 else None,
+            "traffic_source": (pmc3["source"] + ": PMC bytes per algorithmic byte of the same kernel source at 1 M instances, scaled to this shard's algorithmic bytes"
+                               if pmc3 else (f"stale: {stale3} was collected from an older kernel source" if stale3 else None)),
             "algorithmic_bytes_per_launch": kb, "kernel_ms": kms,
             "note": "the shard kernel of rank 0 alone (wall clock incl. host launch); the step as a whole is bound by the all-gather over xGMI",
         }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the skinned frame (BASELINE config 5 extension) K times; prints wall-clock per frame.
-usage: tools/skin_bench.py [n] [frames]"""
+usage: tools/skin_bench.py [n] [frames] [both | palette | bounds]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from renderer_amd.pipeline import make_frame
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256_000
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+which = sys.argv[3] if len(sys.argv) > 3 else "both"
 dev = torch.device("cuda", 0)
 s = scene.make_skinned_scene(n)
 sk = s["skeleton"]
@@ -35,6 +36,8 @@ frame = make_frame(s["planes"], s["cam_pos"])
 kw = dict(model=model.data_ptr(), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(),
           draw_index_total=scal.data_ptr() + 4)
 for variant, pal in (("with palette", palette.data_ptr()), ("bounds only", 0)):
+    if which != "both" and not variant.endswith(which) and not variant.startswith(which):
+        continue
     for _ in range(5):
         p.run_skinned(frame, palette=pal, async_=True, **kw)
     p.wait()
