@@ -118,6 +118,7 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_tmp_cmds);
     (void)hipFree(sl.d_tmp_src);
     (void)hipFree(sl.d_tmp_blocks);
+    (void)hipFree(sl.d_tmp_final);
     (void)hipFree(sl.d_part_status);
     (void)hipFree(sl.d_skin_box);
     (void)hipFree(sl.d_frame_ring);

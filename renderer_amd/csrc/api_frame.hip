@@ -222,6 +222,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
     if (!sl.d_tmp_cmds) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_cmds, cap * 20));
     if (!sl.d_tmp_src) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_src, cap * 4));
     if (!sl.d_tmp_blocks) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_blocks, (cap / 1024 + 1) * 4));
+    if (!sl.d_tmp_final) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_final, cap * 4));
     a.cmds = sl.d_tmp_cmds;
     a.draw_count = sl.d_scalars + 2;
     a.src_index_offset = sl.d_tmp_src;
@@ -298,10 +299,12 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         }
         mip::TrianglePartsArgs pa{};
         pa.t = t;
+        pa.t.final_index_count = sl.d_tmp_final;
         pa.part_status = sl.d_part_status;
         pa.epoch = ++sl.tri_epoch;
 #ifdef MIP_DEBUG_STAMPS
         if (const char* env = std::getenv("MIP_DEBUG_TILE_ORDER")) pa.debug_reverse = std::strcmp(env, "reverse") == 0 ? 1u : 0u;
+        if (const char* env = std::getenv("MIP_DEBUG_SKIP_PART")) pa.debug_skip_part = (uint32_t)std::atoi(env) % mip::kTriParts + 1u;
 #endif
         mip::launch_triangle_cull_parts(plan.tri_blocks, stream, pa);
       } else if (plan.tri == mip::TriangleKernel::block) {
@@ -316,6 +319,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       if (plan.recompact == mip::Recompact::single) {
         mip::RecompactArgs r{};
         r.in_cmds = sl.d_tmp_cmds;
+        r.index_count = plan.tri == mip::TriangleKernel::parts ? sl.d_tmp_final : nullptr;
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;
@@ -323,6 +327,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       } else {
         mip::RecompactWideArgs r{};
         r.in_cmds = sl.d_tmp_cmds;
+        r.index_count = plan.tri == mip::TriangleKernel::parts ? sl.d_tmp_final : nullptr;
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;

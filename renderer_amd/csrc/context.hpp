@@ -40,6 +40,7 @@ struct MipContext {
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
     uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
+    uint32_t* d_tmp_final = nullptr;         //                     parts kernel: each command's final indexCount (never written into the command)
     unsigned long long* d_part_status = nullptr;  //                small frames: one granule per (command, part)
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}

@@ -34,12 +34,17 @@ struct TriangleArgs {
   uint32_t first_instance_base;
   uint32_t* error_flag;
   uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
+  uint32_t* final_index_count;    // parts kernel only: where a command's final indexCount goes (see RecompactArgs.index_count)
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
   float pv[16];
 };
 
 struct RecompactArgs {
   const uint32_t* in_cmds;
+  const uint32_t* index_count;  // per command: its indexCount after the triangle stage — or null: it has been written into in_cmds itself.
+                                // The parts kernel must NOT rewrite the command in place: a part of command c that starts late (its
+                                // successors have long computed its survivors themselves and finished) still reads the command's
+                                // ORIGINAL indexCount to find its triangle range (found in round 4 by the fault-injection test).
   const uint32_t* in_count;
   uint32_t* out_cmds;
   uint32_t* out_count;
@@ -47,6 +52,7 @@ struct RecompactArgs {
 
 struct RecompactWideArgs {
   const uint32_t* in_cmds;
+  const uint32_t* index_count;  // as RecompactArgs.index_count
   const uint32_t* in_count;
   uint32_t* out_cmds;
   uint32_t* out_count;
@@ -63,6 +69,7 @@ struct TrianglePartsArgs {
   uint32_t epoch;                   // unique per launch on this frame slot, never 0
 #ifdef MIP_DEBUG_STAMPS
   uint32_t debug_reverse;           // diagnostic build only: work items are taken from the LAST one down (later parts first)
+  uint32_t debug_skip_part;         // diagnostic build only: part (value - 1) of every command never publishes (0 = off): its successors count it themselves
 #endif
 };
 

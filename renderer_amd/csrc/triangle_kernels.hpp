@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_
 // compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
 // dropped, order kept. One workgroup of kThreads threads walks the (already dense) list.
 template <uint32_t kThreads>
-__device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, uint32_t count, uint32_t* out_cmds, uint32_t* out_count,
-                                                   uint32_t (&s_totals)[kThreads / 64], uint32_t& s_running) {
+__device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, const uint32_t* index_count, uint32_t count, uint32_t* out_cmds,
+                                                   uint32_t* out_count, uint32_t (&s_totals)[kThreads / 64], uint32_t& s_running) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) s_running = 0;
   __syncthreads();
@@ -233,6 +233,7 @@ __device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, uint
     uint32_t w[kCmdWords];
 #pragma unroll
     for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? in_cmds[(size_t)k * kCmdWords + f] : 0u;
+    if (index_count && valid) w[0] = index_count[k];
     const bool keep = valid && w[0] > 0u;
     const unsigned long long mask = __ballot(keep);
     if (lane == 0) s_totals[wave] = (uint32_t)__popcll(mask);
@@ -260,7 +261,7 @@ __device__ __forceinline__ void recompact_commands(const uint32_t* in_cmds, uint
 __global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs a) {
   __shared__ uint32_t s_totals[16];
   __shared__ uint32_t s_running;
-  recompact_commands<1024>(a.in_cmds, *a.in_count, a.out_cmds, a.out_count, s_totals, s_running);
+  recompact_commands<1024>(a.in_cmds, a.index_count, *a.in_count, a.out_cmds, a.out_count, s_totals, s_running);
 }
 
 // Large frames: the same re-compaction over many workgroups, as three small launches — per-block
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(1024) void mip_recompact_count_kernel(const Recompa
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t count = *a.in_count;
   const uint32_t k = blockIdx.x * 1024u + tid;
-  const bool keep = k < count && a.in_cmds[(size_t)k * kCmdWords] > 0u;
+  const bool keep = k < count && (a.index_count ? a.index_count[k] : a.in_cmds[(size_t)k * kCmdWords]) > 0u;
   const unsigned long long mask = __ballot(keep);
   if (lane == 0) s_totals[wave] = (uint32_t)__popcll(mask);
   __syncthreads();
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(1024) void mip_recompact_scatter_kernel(const Recom
   uint32_t w[kCmdWords];
 #pragma unroll
   for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? a.in_cmds[(size_t)k * kCmdWords + f] : 0u;
+  if (a.index_count && valid) w[0] = a.index_count[k];
   const bool keep = valid && w[0] > 0u;
   const unsigned long long mask = __ballot(keep);
   if (lane == 0) s_totals[wave] = (uint32_t)__popcll(mask);
@@ -521,7 +523,12 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
 
     // ---- publish, then the survivors of the earlier parts of this command ----
     unsigned long long* status = pa.part_status + (size_t)c * kTriParts;
-    if (tid == 0)
+#ifdef MIP_DEBUG_STAMPS
+    const bool skip_publish = pa.debug_skip_part == part + 1u;  // fault injection: this part never publishes
+#else
+    const bool skip_publish = false;
+#endif
+    if (tid == 0 && !skip_publish)
       __hip_atomic_store(&status[part], ((unsigned long long)pa.epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t prefix = 0;
     if (wave == 0) {
@@ -584,7 +591,9 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
           dst[0] = i0[k]; dst[1] = i1[k]; dst[2] = i2[k];
         }
     }
-    if (part == kTriParts - 1u && tid == 0) a.cmds[c * kCmdWords + 0] = (prefix + total) * 3u;  // the command's final indexCount
+    // the command's final indexCount — beside the command, never into it: a part of this command that has not started yet (its
+    // successors have helped themselves past it) still needs the ORIGINAL indexCount to find its triangles
+    if (part == kTriParts - 1u && tid == 0) a.final_index_count[c] = (prefix + total) * 3u;
   }
 }
 

@@ -199,10 +199,12 @@ def test_triangle_cull_at_baseline_sizes(ra, oracle_mod, config, n):
     assert 0.2 < survivors / int(r["draw_cmds"]["indexCount"].astype(np.int64).sum()) < 0.8
 
 
-def test_parts_kernel_in_reverse_order_helps_itself(oracle_mod):
+@pytest.mark.parametrize("fault", ["reverse", "skip"])
+def test_parts_kernel_does_not_depend_on_who_runs_when(oracle_mod, fault):
     """The parts kernel (16 work items per command, a part writes its survivors behind those of the earlier parts of its
-    command) with the work items dealt from the LAST one down (diagnostic build): every part finds its predecessors
-    unpublished, counts their survivors itself and the stream still equals the oracle's — no wait depends on another
+    command) in the diagnostic build, with the work items dealt from the LAST one down ("reverse": later parts start first),
+    and with one part of every command that NEVER publishes ("skip": its successors have to count its survivors
+    themselves — MipTimings.prefix_helps says they did): the stream still equals the oracle's. No wait depends on another
     workgroup ever running (rounds 2-3: a bounded wait, MIP_ERR_TIMEOUT and the kernel switched off for the context)."""
     import os
     import subprocess
@@ -215,7 +217,10 @@ import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 os.environ["MIP_LIBRARY"] = os.path.join(sys.argv[1], "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
 os.environ["MIP_TUNE_TRI_PARTS_MAX"] = "100000000"
-os.environ["MIP_DEBUG_TILE_ORDER"] = "reverse"
+if sys.argv[2] == "reverse":
+    os.environ["MIP_DEBUG_TILE_ORDER"] = "reverse"
+else:
+    os.environ["MIP_DEBUG_SKIP_PART"] = "3"
 import numpy as np
 import oracle, renderer_amd
 from test_gpu_triangles import _oracle, _run_gpu
@@ -228,9 +233,12 @@ for config, n in ((3, 3000), (2, 700)):
     capacity = r0["draw_index_total"] + 3
     r, want_cmds, want_out = _oracle(oracle, s, vertices, indices, pv, capacity)
     got_cmds, count, total, got_out = _run_gpu(renderer_amd, s, vertices, indices, pv, capacity, frames=2)
-    assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes() and np.array_equal(got_out, want_out), (config, n)
-    assert _run_gpu.last_timings["prefix_helps"] > 0, _run_gpu.last_timings
+    assert count == len(want_cmds), (config, n, count, len(want_cmds))
+    assert got_cmds.tobytes() == want_cmds.tobytes(), (config, n, "commands", int((got_cmds != want_cmds).sum()))
+    assert np.array_equal(got_out, want_out), (config, n, "index stream", int((got_out != want_out).sum()), int(np.nonzero(got_out != want_out)[0][0]))
+    if sys.argv[2] == "skip":   # (in reverse order the predecessors are usually published in time by their own workgroups)
+        assert _run_gpu.last_timings["prefix_helps"] > 0, _run_gpu.last_timings
 print("PARTS OK")
 '''
-    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code, root, fault], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "PARTS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
