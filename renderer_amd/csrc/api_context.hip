@@ -105,6 +105,7 @@ void free_all(MipContext* ctx) {
   (void)hipFree(ctx->d_mesh_id);
   (void)hipFree(ctx->d_meshes);
   (void)hipFree(ctx->d_census);
+  (void)hipFree(ctx->d_help);
   (void)hipFree(ctx->d_mesh_draw);
   (void)hipFree(ctx->d_blas);
   (void)hipFree(ctx->d_vertices);
@@ -209,6 +210,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipHostMalloc(&ctx->h_error, 64, hipHostMallocMapped));
     std::memset(ctx->h_error, 0, 64);
     MIP_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_error, ctx->h_error, 0));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_help, 64));
+    MIP_HIP(ctx, hipMemset(ctx->d_help, 0, 64));
 #ifdef MIP_DEBUG_STAMPS
     MIP_HIP(ctx, hipMalloc(&ctx->d_stamps, tiles_cap * 64));
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
@@ -525,15 +528,19 @@ const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "nul
 
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out) {
   if (!ctx || !out) return MIP_ERR_INVALID_ARGUMENT;
-  ctx->timings.prefix_helps = ((volatile uint32_t*)ctx->h_error)[mip::kHelpCounterWord];  // the device adds, the host only reads
+  if (int32_t rc = bind_device(ctx)) return rc;
+  uint32_t helps = 0;  // the device adds (kernels that are in flight may still be adding), the host only reads
+  MIP_HIP(ctx, hipMemcpy(&helps, ctx->d_help, 4, hipMemcpyDeviceToHost));
+  ctx->timings.prefix_helps = helps;
   *out = ctx->timings;
   return MIP_OK;
 }
 
 int32_t mip_reset_timings(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
+  if (int32_t rc = bind_device(ctx)) return rc;
   // (the help counter is written by kernels that may be in flight: it is cleared only when nothing is)
-  if (!ctx->pending_async) ((volatile uint32_t*)ctx->h_error)[mip::kHelpCounterWord] = 0;
+  if (!ctx->pending_async) MIP_HIP(ctx, hipMemset(ctx->d_help, 0, 4));
   ctx->timings = MipTimings{};
   return MIP_OK;
 }

@@ -89,6 +89,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.start1 = sl.d_status + ctx->start1_offset_words;
   a.groups_cap = ctx->groups_cap;
   a.error_flag = ctx->d_error;
+  a.help_counter = ctx->d_help;
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
@@ -283,6 +284,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       t.capacity = out->culled_index_capacity;
       t.first_instance_base = frame->first_instance_base;
       t.error_flag = ctx->d_error;
+      t.help_counter = ctx->d_help;
       t.ticket = sl.d_scalars + 3;
       t.geometry_finite = ctx->geometry_finite ? 1u : 0u;
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
@@ -643,6 +645,7 @@ static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const Mi
       w.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
       w.epoch = e;
       w.error_flag = ctx->d_error;
+      w.help_counter = ctx->d_help;
       w.bitmap = outs[v].visible_bitmap;
       w.cmds = (uint32_t*)outs[v].draw_cmds;
       w.draw_count = outs[v].draw_count;

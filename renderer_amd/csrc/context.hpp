@@ -120,7 +120,8 @@ struct MipContext {
   uint64_t nonfinite_instances = 0;
   float box_abs = 0.f;  // largest sum of |box coordinates| over the mesh table (the census' overflow bound)
   uint32_t* d_census = nullptr;
-  uint32_t* h_error = nullptr;  // pinned, device-visible: error words [0, kErrWords) + the help counter (kHelpCounterWord)
+  uint32_t* h_error = nullptr;  // pinned, device-visible: error words [0, kErrWords)
+  uint32_t* d_help = nullptr;   // device memory: helped tile aggregates (MipTimings.prefix_helps); read back by mip_get_timings
   uint32_t* d_error = nullptr;  // device alias of h_error
   uint32_t carried_error_bits = 0;  // error bits a synchronous call saw while asynchronous work was in flight: reported then AND by the next mip_wait
   // staging for MIP_OUT_HOST

@@ -88,7 +88,8 @@ struct KernelArgs {
   unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
   uint32_t groups_cap;
   uint32_t group_shift;         // log2(tiles per group), <= 6
-  uint32_t* error_flag;         // host-mapped: error words + the help counter
+  uint32_t* error_flag;         // host-mapped error words
+  uint32_t* help_counter;       // DEVICE memory: tile aggregates that waiting tiles computed themselves (MipTimings.prefix_helps)
   uint32_t n;
   uint32_t n_tiles;
   uint32_t epoch;               // 1 .. 2^31-1, unique per launch
@@ -144,7 +145,6 @@ constexpr uint32_t kErrIndexOverflow = 4u;   // word 2: culled_index_buffer too 
 constexpr uint32_t kErrWireRecord = 8u;      // word 3: a wire record names a mesh outside the table
 constexpr uint32_t kErrSemaphore = 32u;      // word 5: written by the HOST (a stream-ordered wait on an external semaphore expired)
 constexpr uint32_t kErrWords = 6;
-constexpr uint32_t kHelpCounterWord = 8;     // word 8 of the same block is not an error: it counts helped tiles (resolve_prefix)
 __device__ __forceinline__ void raise_error(uint32_t* error_flag, uint32_t bit) {
   __hip_atomic_store(error_flag + (31 - __builtin_clz(bit)), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -457,7 +457,7 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
 // accumulators, so those stay exact). This is decoupled look-back with a fallback: the launch makes progress in ANY
 // order the hardware starts workgroups in, with no ticket at the head of every workgroup (11 ns each, serialised) and
 // no second launch. In-order dispatch — what an idle chip does — is now a performance property (no helps), not a
-// correctness assumption. Helps are counted in a host-mapped word (MipTimings.prefix_helps).
+// correctness assumption. Helps are counted in a device word (MipTimings.prefix_helps).
 // Round 3 and before: the same polls bounded at 0.5 s, then MIP_ERR_TIMEOUT, a ticketed re-issue and a recovery path.
 constexpr uint32_t kPatientPolls = 64;
 constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
@@ -473,41 +473,37 @@ __device__ __forceinline__ bool granule_ready(const A& a, unsigned long long g) 
 template <class A, class Help>
 __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, uint32_t count, uint32_t lane, uint32_t spread,
                                                   Help& help, uint32_t& c, uint32_t& s) {
-  // (c and s are wave-uniform; nothing per lane stays alive across a help: the cold path must fit the hot path's registers)
-  unsigned long long missing;
-  {
-    uint32_t myc = 0, mys = 0;
-    bool have = lane >= count;
-    if (!have) {
-      const unsigned long long g = status_load(&a.status0[first + lane]);
-      if (granule_ready(a, g)) { have = true; myc = (uint32_t)g & ((1u << kTileCountBits) - 1u); mys = (uint32_t)(g >> 32); }
-    }
-    missing = __ballot(!have);
-    c += wave_sum(myc);
-    s += wave_sum(mys);
-  }
+  // (c and s are wave-uniform, and so is the set of tiles still to be summed; nothing per lane stays alive across a help: the
+  //  cold path must fit the hot path's registers)
+  unsigned long long pending = count >= 64u ? ~0ull : ((1ull << count) - 1ull);
   const uint32_t rot = spread & 63u;
 #pragma nounroll
-  while (missing) {  // wave-uniform
-    const unsigned long long turned = rot ? ((missing >> rot) | (missing << (64u - rot))) : missing;
+  while (pending) {  // wave-uniform
+    // every pass looks at ALL the tiles still missing with one coalesced load: what other waiting tiles have published since the
+    // last pass is taken from them, and only ONE tile per pass is computed here
+    const bool mine = (pending >> lane) & 1ull;
+    unsigned long long g = 0;
+    if (mine) g = status_load(&a.status0[first + lane]);
+    const bool ok = mine && granule_ready(a, g);
+    c += wave_sum(ok ? ((uint32_t)g & ((1u << kTileCountBits) - 1u)) : 0u);
+    s += wave_sum(ok ? (uint32_t)(g >> 32) : 0u);
+    pending &= ~__ballot(ok);
+    if (!pending) break;
+    const unsigned long long turned = rot ? ((pending >> rot) | (pending << (64u - rot))) : pending;
     const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__builtin_ctzll(turned) + rot) & 63u));
     const uint32_t u = first + pick;
-    const unsigned long long g = status_load(&a.status0[u]);  // somebody may have published it meanwhile (uniform address)
-    uint32_t uc = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)g & ((1u << kTileCountBits) - 1u)));
-    uint32_t us = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(g >> 32));
-    if (!granule_ready(a, g)) {  // uniform
-      const unsigned long long agg = help(u);  // {sum : 32 | count : 32}, wave-uniform
-      uc = (uint32_t)agg;
-      us = (uint32_t)(agg >> 32);
-      if (lane == 0u) {
-        __hip_atomic_store(&a.status0[u], ((unsigned long long)us << 32) | ((unsigned long long)a.epoch << kTileCountBits) | uc,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)__hip_atomic_fetch_add(a.error_flag + kHelpCounterWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+    const unsigned long long agg = help(u);  // {sum : 32 | count : 32}, wave-uniform
+    const uint32_t uc = (uint32_t)agg, us = (uint32_t)(agg >> 32);
+    if (lane == 0u) {
+      __hip_atomic_store(&a.status0[u], ((unsigned long long)us << 32) | ((unsigned long long)a.epoch << kTileCountBits) | uc,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a DEVICE word: as a system-scope atomic on the host-mapped error block every help cost ~1 us of PCIe round trip, serialised
+      //  on one address — 10 000 helps per frame were 10 ms, and that, not the helping, was the degraded mode's cost)
+      (void)__hip_atomic_fetch_add(a.help_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     c += uc;
     s += us;
-    missing &= ~(1ull << pick);
+    pending &= ~(1ull << pick);
   }
 }
 
@@ -545,10 +541,17 @@ __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile
       s += wave_sum(mys);
       open = __ballot(valid && !complete);
     }
+    // wave-uniform: groups some of whose tiles have not added yet — tile by tile. Hundreds of waiting tiles need the same missing
+    // aggregates: every one of them takes the open groups in an order of its own (a rotation hashed from its tile number, and
+    // within a group another one), so that together they cover the missing set once instead of all walking it from the bottom —
+    // what one publishes the others find (tiles in scrambled order, 1 M instances: 57 k helps and 19 ms per frame before,
+    // profiles/r04_selfhelp_any_order.txt for after).
+    const uint32_t rot = (tile * 2654435761u) >> 26;
 #pragma nounroll
-    while (open) {  // wave-uniform: groups some of whose tiles have not added yet — tile by tile
-      const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(open));
-      sum_tiles_helping(a, (gb + pick) << a.group_shift, per_group, lane, tile, help, c, s);
+    while (open) {
+      const unsigned long long turned = rot ? ((open >> rot) | (open << (64u - rot))) : open;
+      const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__builtin_ctzll(turned) + rot) & 63u));
+      sum_tiles_helping(a, (gb + pick) << a.group_shift, per_group, lane, tile * 7u + pick, help, c, s);
       open &= ~(1ull << pick);
     }
   }

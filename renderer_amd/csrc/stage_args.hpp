@@ -33,6 +33,7 @@ struct TriangleArgs {
   unsigned long long capacity;    // in indices
   uint32_t first_instance_base;
   uint32_t* error_flag;
+  uint32_t* help_counter;         // device word: parts whose survivors a waiting part counted itself (MipTimings.prefix_helps)
   uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
   uint32_t* final_index_count;    // parts kernel only: where a command's final indexCount goes (see RecompactArgs.index_count)
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
@@ -138,6 +139,7 @@ struct ViewArgs {
   uint32_t group_shift;
   uint32_t epoch;
   uint32_t* error_flag;
+  uint32_t* help_counter;  // device word (MipTimings.prefix_helps)
 #ifdef MIP_DEBUG_STAMPS
   unsigned long long* stamps;  // never set: keeps the shared prefix routines compiling in the diagnostic build
 #endif

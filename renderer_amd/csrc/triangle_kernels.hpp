@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
           g = ((unsigned long long)pa.epoch << 32) | survivors;
           if (lane == 0u) {
             __hip_atomic_store(&status[p], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add(a.error_flag + kHelpCounterWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            (void)__hip_atomic_fetch_add(a.help_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         if (lane == p) got = (uint32_t)g;
