@@ -97,6 +97,7 @@ void free_all(MipContext* ctx) {
   for (auto& sl : ctx->slots)
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
   drop_graphs(ctx);
+  (void)interop_drain(ctx);  // the streams have drained: let queued semaphore signals go out before the helper threads stop
   interop_release(ctx);
   comm_release(ctx);
   (void)hipFree(ctx->d_pos);

@@ -1,6 +1,8 @@
 // api_interop.hip — C ABI of the instance pipeline, part 4 of 4: zero-copy interop with the renderer's own Vulkan
 // allocations and queues: memory exported as a POSIX fd (dma-buf on amdgpu) mapped into the HIP
 // device, and timeline / binary semaphores exported as fds waited for and signalled in stream order.
+#include <atomic>
+
 #include "context.hpp"
 
 #include <drm/drm.h>  // DRM sync objects: what an exported Vulkan semaphore fd is on amdgpu (kernel uapi, no libdrm)
@@ -198,7 +200,8 @@ struct MipContext::SemaphoreWorkers {
   std::mutex m;
   std::condition_variable wake_waiter, wake_signaller, idle;
   std::deque<Request> waits, signals;
-  bool waiter_busy = false, signaller_busy = false, stop = false;
+  bool waiter_busy = false, signaller_busy = false;
+  std::atomic<bool> stop{false};  // set under m (the condition variables read it there); the signaller's spin reads it without
   std::thread waiter, signaller;
   int drm_fd = -1;
   volatile uint32_t* error_word = nullptr;
@@ -239,7 +242,7 @@ static void signaller_main(MipContext::SemaphoreWorkers* w) {
     uint32_t polls = 0;
     bool reached = true;
     while (__atomic_load_n(&rq.sem->words[1], __ATOMIC_ACQUIRE) < rq.seq) {
-      if (__atomic_load_n(&w->stop, __ATOMIC_RELAXED)) { reached = false; break; }
+      if (w->stop.load(std::memory_order_relaxed)) { reached = false; break; }
       if (++polls < 4096u) continue;  // a frame is tens of microseconds: spin that long ...
       timespec now;
       clock_gettime(CLOCK_MONOTONIC, &now);
