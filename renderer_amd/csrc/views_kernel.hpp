@@ -92,7 +92,11 @@ __device__ __forceinline__ unsigned long long help_view_aggregate(uint32_t v, ui
 // kGeneral = false: the upload-time census found every instance finite and separable-safe (as for the frame kernel).
 template <bool kGeneral>
 __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArgs a) {
-  __shared__ uint32_t s_cmd[kMaxViews][kTile * kCmdWords];
+  // four words per staged command (instanceCount is the constant 1: the copy-out writes it): 16 KB for the four views, which
+  // with the VGPRs lets EIGHT workgroups share a CU (five words: 20.6 KB, seven; the launch is bound by tiles in flight x
+  // a tile's latency, not by bytes)
+  constexpr uint32_t kStaged = 4;
+  __shared__ __attribute__((aligned(16))) uint32_t s_cmd[kMaxViews][kTile * kStaged];
   __shared__ uint32_t s_wave_count[kMaxViews][kWaves], s_wave_sum[kMaxViews][kWaves];
   static_assert(kWaves >= kMaxViews, "one wave per view finishes that view");
 
@@ -177,12 +181,9 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
 #pragma unroll
       for (uint32_t w = 0; w < kWaves; ++w)
         if (w < wave) { off_count += s_wave_count[v][w]; off_sum += s_wave_sum[v][w]; }
-      uint32_t* c = &s_cmd[v][(off_count + rank[v]) * kCmdWords];
-      c[0] = len[v];                                // indexCount
-      c[1] = 1u;                                    // instanceCount
-      c[2] = off_sum + excl_sum[v];                 // firstIndex (tile-relative)
-      c[3] = (uint32_t)vertex_offset;               // vertexOffset
-      c[4] = a.view[v].first_instance_base + i;     // firstInstance = draw_index
+      // {indexCount, firstIndex (tile-relative), vertexOffset, firstInstance = draw_index}: one ds_write_b128
+      *reinterpret_cast<uint4*>(&s_cmd[v][(off_count + rank[v]) * kStaged]) =
+          make_uint4(len[v], off_sum + excl_sum[v], (uint32_t)vertex_offset, a.view[v].first_instance_base + i);
     }
   }
   __syncthreads();
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
       const uint32_t words = s_tile_count[v] * kCmdWords;
       for (uint32_t j = tid; j < words; j += kTile) {
         const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
-        uint32_t val = s_cmd[v][j];
+        uint32_t val = f == 1u ? 1u : s_cmd[v][k * kStaged + (f ? f - 1u : 0u)];
         if (f == 2u) val += first_index_add;
         out[j] = val;
       }
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   const uint32_t words = tile_count * kCmdWords;
   for (uint32_t j = lane; j < words; j += 64u) {
     const uint32_t k = j / kCmdWords, f = j - k * kCmdWords;
-    uint32_t val = s_cmd[my_view][j];
+    uint32_t val = f == 1u ? 1u : s_cmd[my_view][k * kStaged + (f ? f - 1u : 0u)];  // instanceCount = 1 (generate_work.comp:63)
     if (f == 2u) val += first_index_add;
     out[j] = val;
   }
