@@ -534,6 +534,22 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
                     "packed instructions (its translation unit is built without the SLP vectoriser). Round 3 printed 0.98 here against a ceiling "
                     "of one instruction per 4 cycles, which is what ONE wave sustains, not what the SIMD does",
         }
+        c = doc["counters_per_launch"]
+        if c.get("SQ_INSTS_VMEM_RD") and c.get("GRBM_GUI_ACTIVE"):
+            # second reading from the same PMC pass: how busy the vector-load path is. Ceilings for the SAME instruction
+            # (global_load_dwordx3, 12 B per lane) measured by tools/micro/l1_line_rate.hip (profiles/r04_l1_line_rate.txt), in
+            # wave-loads per cycle per CU at 8 waves per SIMD: 0.114 when every load hits the L1 (any stride up to 48 B);
+            # L2-served: 0.134 consecutive vec3, 0.039 every 4th vertex, 0.016-0.019 a line per lane.
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            rate = c["SQ_INSTS_VMEM_RD"] / 256.0 / cycles
+            row["roofline"]["vector_load_path"] = {
+                "wave_loads_per_cycle_per_cu": rate, "shader_cycles": cycles,
+                "l1_accesses_per_wave_load": (c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"]) if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                "l1_hit_rate": (1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]) if c.get("TCP_TCC_READ_REQ_sum") and c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+                "measured_ceilings_wave_loads_per_cycle_per_cu": {"l1_hits": 0.114, "l2_consecutive_vec3": 0.134, "l2_every_4th_vertex": 0.039, "l2_a_line_per_lane": 0.017},
+                "note": "the gathers use 0.25-0.7 of what the load path sustains for comparable access patterns: neither VALU issue (frac above) nor the "
+                        "load path is saturated, and deeper pipelining of the gathers changes nothing (profiles/r04_triangle_bound_experiments.txt)",
+            }
     if with_cpu:
         import oracle
 

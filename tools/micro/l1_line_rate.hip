@@ -1,0 +1,131 @@
+// l1_line_rate.hip — how many cache lines per cycle does one CU's vector L1 look up for a gathered load?
+//
+// The per-triangle kernel (row f-1) gathers three packed vec3 positions per lane and step; its PMC pass shows
+// TCP_TOTAL_CACHE_ACCESSES = 0.89 per cycle per CU (profiles/r04_triangle_cull_100k_rows_pmc_summary.json) and its time doubles
+// when the triangle order is shuffled (every lane its own line) although the arithmetic is the same. This program measures the
+// ceiling that figure is a fraction of: waves issue `global_load_dwordx3` (12 B per lane, as the kernel's gathers) from an
+// L2-resident buffer with a chosen LANE STRIDE — 12 B (consecutive packed vec3: ~6 lines of 128 B per wave-load), 48 B, 128 B
+// and 256 B (every lane its own line) and a pseudo-random line per lane — eight waves per SIMD on every CU, nothing else in
+// the loop. Reported: wave-loads per second, lanes' distinct 128-byte and 64-byte lines per wave-load, and lines per cycle per
+// CU at the clock measured by s_memtime against s_memrealtime.
+//
+//   hipcc --offload-arch=gfx950 -O2 tools/micro/l1_line_rate.hip -o /tmp/l1_line_rate && /tmp/l1_line_rate
+// Output = profiles/r04_l1_line_rate.txt.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#define CHECK(x)                                                                          \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      std::fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));                 \
+      std::exit(1);                                                                       \
+    }                                                                                     \
+  } while (0)
+
+struct Stamp {
+  unsigned long long cycles, ticks;
+};
+
+constexpr int kLoadsPerIter = 8;
+constexpr int kIters = 512;
+constexpr unsigned kBufferBytes = 2u << 20;  // 2 MiB: inside one XCD's 4 MiB L2, far beyond the 32 KiB L1
+
+// offsets[lane] = byte offset of the lane's 12 bytes inside a 16 KiB window; the window moves through the buffer per load
+__global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsigned* offsets, Stamp* out, float* sink, unsigned window_mask) {
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const unsigned my = offsets[lane];
+  unsigned window = (wave_global * 40503u) & window_mask;
+  float acc = 0.f;
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    float x[kLoadsPerIter][3];
+#pragma unroll
+    for (int k = 0; k < kLoadsPerIter; ++k) {
+      const float* p = reinterpret_cast<const float*>(buf + (size_t)window * 16384u + my);
+      x[k][0] = p[0]; x[k][1] = p[1]; x[k][2] = p[2];  // one global_load_dwordx3 (checked in the ISA), as the triangle kernel's gathers
+      window = (window + 1u) & window_mask;
+    }
+#pragma unroll
+    for (int k = 0; k < kLoadsPerIter; ++k) acc += x[k][0] + x[k][1] + x[k][2];
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (acc == 123.456f) sink[0] = acc;
+  if (lane == 0) {
+    out[wave_global].cycles = c1 - c0;
+    out[wave_global].ticks = r1 - r0;
+  }
+}
+
+int main() {
+  CHECK(hipSetDevice(0));
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  char* buf;
+  unsigned* d_off;
+  Stamp* d_out;
+  float* d_sink;
+  CHECK(hipMalloc(&buf, kBufferBytes + 65536));
+  CHECK(hipMemset(buf, 0, kBufferBytes + 65536));
+  CHECK(hipMalloc(&d_off, 64 * 4));
+  CHECK(hipMalloc(&d_sink, 64));
+  std::printf("# %s, %d CUs; %d wave-loads of 12 B per lane per wave, 8 waves per SIMD, buffer %u KiB (L2-resident)\n", prop.gcnArchName, cus,
+              kIters * kLoadsPerIter, kBufferBytes >> 10);
+  struct Pattern { const char* name; int stride; } patterns[] = {
+      {"lane stride 12 B (consecutive packed vec3)", 12}, {"lane stride 24 B", 24},   {"lane stride 48 B (every 4th vertex)", 48},
+      {"lane stride 64 B", 64},                           {"lane stride 128 B", 128}, {"lane stride 256 B (a line per lane)", 256},
+      {"random 12-byte slot of the 16 KiB window per lane", -1}};
+  for (unsigned windows : {1u, 2u, kBufferBytes / 16384u})
+  for (int waves_per_simd : {8, 4}) {
+    if (windows != kBufferBytes / 16384u && waves_per_simd != 8) continue;
+    std::printf("# working set %u KiB (%s)\n", windows * 16u, windows <= 2u ? "fits the CU's 32 KiB L1: every load hits" : "served by the L2");
+    const int blocks = cus * waves_per_simd;  // 256 threads = one wave per SIMD of a CU per block
+    CHECK(hipMalloc(&d_out, sizeof(Stamp) * (size_t)blocks * 4));
+    for (const Pattern& p : patterns) {
+      std::vector<unsigned> off(64);
+      unsigned seed = 12345u;
+      for (int l = 0; l < 64; ++l) {
+        if (p.stride > 0) off[l] = (unsigned)(l * p.stride);
+        else { seed = seed * 1664525u + 1013904223u; off[l] = ((seed >> 8) % (16384u / 12u - 1u)) * 12u; }
+      }
+      std::set<unsigned> l128, l64;
+      for (int l = 0; l < 64; ++l)
+        for (unsigned b : {off[l], off[l] + 11u}) { l128.insert(b / 128u); l64.insert(b / 64u); }
+      CHECK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+      double best = 0, clock_mhz = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, 0, buf, d_off, d_out, d_sink, windows - 1u);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        std::vector<Stamp> h((size_t)blocks * 4);
+        CHECK(hipMemcpy(h.data(), d_out, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> c(h.size()), t(h.size());
+        for (size_t k = 0; k < h.size(); ++k) { c[k] = h[k].cycles; t[k] = h[k].ticks; }
+        std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end());
+        std::nth_element(t.begin(), t.begin() + t.size() / 2, t.end());
+        // per CU: 4 SIMDs x waves_per_simd waves, each kIters * kLoadsPerIter wave-loads in the median wave's cycles
+        const double loads_per_cycle_per_cu = 4.0 * waves_per_simd * kIters * kLoadsPerIter / (double)c[c.size() / 2];
+        if (loads_per_cycle_per_cu > best) {
+          best = loads_per_cycle_per_cu;
+          clock_mhz = (double)c[c.size() / 2] / ((double)t[t.size() / 2] / 100.0);
+        }
+      }
+      std::printf("%-52s waves/SIMD %d  lines per wave-load: %2zu of 128 B, %2zu of 64 B   %.4f wave-loads per cycle per CU = %6.3f (128 B) / %6.3f (64 B) "
+                  "lines per cycle per CU   clock %4.0f MHz\n",
+                  p.name, waves_per_simd, l128.size(), l64.size(), best, best * l128.size(), best * l64.size(), clock_mhz);
+      std::fflush(stdout);
+    }
+    CHECK(hipFree(d_out));
+  }
+  return 0;
+}
