@@ -547,7 +547,7 @@ def triangle_leg(torch, renderer_amd, scene, make_frame, s, device, local_rank, 
                 "l1_accesses_per_wave_load": (c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"]) if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
                 "l1_hit_rate": (1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]) if c.get("TCP_TCC_READ_REQ_sum") and c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
                 "measured_ceilings_wave_loads_per_cycle_per_cu": {"l1_hits": 0.114, "l2_consecutive_vec3": 0.134, "l2_every_4th_vertex": 0.039, "l2_a_line_per_lane": 0.017},
-                "note": "the gathers use 0.25-0.7 of what the load path sustains for comparable access patterns: neither VALU issue (frac above) nor the "
+                "note": "the gathers use 0.22-0.72 of what the load path sustains for comparable access patterns: neither VALU issue (frac above) nor the "
                         "load path is saturated, and deeper pipelining of the gathers changes nothing (profiles/r04_triangle_bound_experiments.txt)",
             }
     if with_cpu:

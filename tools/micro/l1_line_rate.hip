@@ -37,6 +37,9 @@ constexpr int kIters = 512;
 constexpr unsigned kBufferBytes = 2u << 20;  // 2 MiB: inside one XCD's 4 MiB L2, far beyond the 32 KiB L1
 
 // offsets[lane] = byte offset of the lane's 12 bytes inside a 16 KiB window; the window moves through the buffer per load
+// kScalarBase: the window's base is made wave-uniform (readfirstlane), so the load is the SGPR-base + 32-bit-VGPR-offset form
+// (global_load_dwordx3 v, v_off, s[base:base+1]) instead of a 64-bit address per lane (global_load_dwordx3 v, v[lo:hi], off).
+template <bool kScalarBase>
 __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsigned* offsets, Stamp* out, float* sink, unsigned window_mask) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -46,16 +49,29 @@ __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsi
   __syncthreads();
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  typedef float v3f __attribute__((ext_vector_type(3)));
   for (int it = 0; it < kIters; ++it) {
-    float x[kLoadsPerIter][3];
+    v3f x[kLoadsPerIter];
 #pragma unroll
     for (int k = 0; k < kLoadsPerIter; ++k) {
-      const float* p = reinterpret_cast<const float*>(buf + (size_t)window * 16384u + my);
-      x[k][0] = p[0]; x[k][1] = p[1]; x[k][2] = p[2];  // one global_load_dwordx3 (checked in the ISA), as the triangle kernel's gathers
+      // (inline assembly: the compiler folds a wave-uniform base back into a 64-bit address per lane)
+      if constexpr (kScalarBase) {
+        const char* base = buf + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)window) * 16384u;
+        // s_nop: the hazard recogniser does not see that this statement READS the SGPR pair a scalar add has just written
+        // (an SALU write needs wait states before a vector-memory instruction uses it as an address: without them the load
+        // goes to a stale address and faults)
+        asm volatile("s_nop 7\n\tglobal_load_dwordx3 %0, %1, %2" : "=v"(x[k]) : "v"(my), "s"(base) : "memory");
+      } else {
+        const char* p = buf + (size_t)window * 16384u + my;
+        asm volatile("s_nop 7\n\tglobal_load_dwordx3 %0, %1, off" : "=v"(x[k]) : "v"(p) : "memory");
+      }
       window = (window + 1u) & window_mask;
     }
+    // the loaded registers are operands of the wait, so nothing reads (or reuses) them before it
+    static_assert(kLoadsPerIter == 8, "operand list below");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
 #pragma unroll
-    for (int k = 0; k < kLoadsPerIter; ++k) acc += x[k][0] + x[k][1] + x[k][2];
+    for (int k = 0; k < kLoadsPerIter; ++k) acc += x[k].x + x[k].y + x[k].z;
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -85,10 +101,12 @@ int main() {
       {"lane stride 12 B (consecutive packed vec3)", 12}, {"lane stride 24 B", 24},   {"lane stride 48 B (every 4th vertex)", 48},
       {"lane stride 64 B", 64},                           {"lane stride 128 B", 128}, {"lane stride 256 B (a line per lane)", 256},
       {"random 12-byte slot of the 16 KiB window per lane", -1}};
-  for (unsigned windows : {1u, 2u, kBufferBytes / 16384u})
+  for (int scalar_base : {0, 1})
+  for (unsigned windows : {1u, kBufferBytes / 16384u})
   for (int waves_per_simd : {8, 4}) {
     if (windows != kBufferBytes / 16384u && waves_per_simd != 8) continue;
-    std::printf("# working set %u KiB (%s)\n", windows * 16u, windows <= 2u ? "fits the CU's 32 KiB L1: every load hits" : "served by the L2");
+    std::printf("# working set %u KiB (%s), address = %s\n", windows * 16u, windows <= 2u ? "fits the CU's 32 KiB L1: every load hits" : "served by the L2",
+                scalar_base ? "SGPR base + 32-bit lane offset" : "64-bit per lane");
     const int blocks = cus * waves_per_simd;  // 256 threads = one wave per SIMD of a CU per block
     CHECK(hipMalloc(&d_out, sizeof(Stamp) * (size_t)blocks * 4));
     for (const Pattern& p : patterns) {
@@ -104,7 +122,8 @@ int main() {
       CHECK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
       double best = 0, clock_mhz = 0;
       for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, 0, buf, d_off, d_out, d_sink, windows - 1u);
+        if (scalar_base) hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks), dim3(256), 0, 0, buf, d_off, d_out, d_sink, windows - 1u);
+        else hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks), dim3(256), 0, 0, buf, d_off, d_out, d_sink, windows - 1u);
         CHECK(hipGetLastError());
         CHECK(hipDeviceSynchronize());
         std::vector<Stamp> h((size_t)blocks * 4);
