@@ -39,7 +39,9 @@ constexpr unsigned kBufferBytes = 2u << 20;  // 2 MiB: inside one XCD's 4 MiB L2
 // offsets[lane] = byte offset of the lane's 12 bytes inside a 16 KiB window; the window moves through the buffer per load
 // kScalarBase: the window's base is made wave-uniform (readfirstlane), so the load is the SGPR-base + 32-bit-VGPR-offset form
 // (global_load_dwordx3 v, v_off, s[base:base+1]) instead of a 64-bit address per lane (global_load_dwordx3 v, v[lo:hi], off).
-template <bool kScalarBase>
+// kValu: independent f32 multiply / add instructions per iteration beside the 8 loads (0 = loads only; kLoads = false: the
+// arithmetic alone) — does the vector-load path overlap with VALU issue, or do the two add up?
+template <bool kScalarBase, int kValu = 0, bool kLoads = true>
 __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsigned* offsets, Stamp* out, float* sink, unsigned window_mask) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -50,10 +52,15 @@ __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsi
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
   typedef float v3f __attribute__((ext_vector_type(3)));
+  float m[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) m[q] = 1.0f + 0.001f * (float)(lane + q);
   for (int it = 0; it < kIters; ++it) {
     v3f x[kLoadsPerIter];
 #pragma unroll
-    for (int k = 0; k < kLoadsPerIter; ++k) {
+    for (int k = 0; k < kLoadsPerIter; ++k) x[k] = v3f{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < (kLoads ? kLoadsPerIter : 0); ++k) {
       // (inline assembly: the compiler folds a wave-uniform base back into a 64-bit address per lane)
       if constexpr (kScalarBase) {
         const char* base = buf + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)window) * 16384u;
@@ -67,6 +74,11 @@ __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsi
       }
       window = (window + 1u) & window_mask;
     }
+#pragma unroll
+    for (int v = 0; v < kValu; ++v) {  // eight independent chains, mul and add alternating: issued while the loads are in flight
+      if (v & 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(m[v & 7]) : "v"(1e-30f));
+      else asm volatile("v_mul_f32 %0, %0, %1" : "+v"(m[v & 7]) : "v"(1.0000001f));
+    }
     // the loaded registers are operands of the wait, so nothing reads (or reuses) them before it
     static_assert(kLoadsPerIter == 8, "operand list below");
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
@@ -75,6 +87,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const char* buf, const unsi
   }
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc += m[q];
   if (acc == 123.456f) sink[0] = acc;
   if (lane == 0) {
     out[wave_global].cycles = c1 - c0;
@@ -143,6 +157,37 @@ int main() {
                   "lines per cycle per CU   clock %4.0f MHz\n",
                   p.name, waves_per_simd, l128.size(), l64.size(), best, best * l128.size(), best * l64.size(), clock_mhz);
       std::fflush(stdout);
+    }
+    CHECK(hipFree(d_out));
+  }
+  // ---- overlap: 8 loads (every 4th vertex, L2-served) + 346 VALU instructions per iteration = two steps of the per-triangle kernel
+  {
+    const int blocks = cus * 8;
+    CHECK(hipMalloc(&d_out, sizeof(Stamp) * (size_t)blocks * 4));
+    std::vector<unsigned> off(64);
+    for (int l = 0; l < 64; ++l) off[l] = (unsigned)(l * 48);
+    CHECK(hipMemcpy(d_off, off.data(), 256, hipMemcpyHostToDevice));
+    auto run = [&](const char* what, auto kernel, unsigned windows) {
+      double best = 1e30;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, buf, d_off, d_out, d_sink, windows - 1u);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+        std::vector<Stamp> h((size_t)blocks * 4);
+        CHECK(hipMemcpy(h.data(), d_out, sizeof(Stamp) * h.size(), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> c(h.size());
+        for (size_t k = 0; k < h.size(); ++k) c[k] = h[k].cycles;
+        std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end());
+        best = std::min(best, (double)c[c.size() / 2] / kIters);
+      }
+      std::printf("%-78s %8.1f cycles per iteration per wave (8 waves per SIMD) = %6.1f cycles of the CU per wave-iteration\n", what, best, best / 32.0);
+    };
+    std::printf("# overlap of the load path with VALU issue: one iteration = 8 gathers at the every-4th-vertex stride and/or 346 independent f32 instructions\n");
+    for (unsigned windows : {1u, kBufferBytes / 16384u}) {
+      std::printf("# working set %u KiB\n", windows * 16u);
+      run("loads only", gather_kernel<false, 0, true>, windows);
+      run("346 VALU instructions only", gather_kernel<false, 346, false>, windows);
+      run("loads + 346 VALU instructions (in flight together)", gather_kernel<false, 346, true>, windows);
     }
     CHECK(hipFree(d_out));
   }
