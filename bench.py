@@ -805,6 +805,16 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
     # next-tier rows (not the headline)
     guarded("triangle_cull_100k", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, not args.no_cpu_baseline))
     guarded("triangle_cull_100k_strips", lambda: triangle_leg(torch, renderer_amd, scene, make_frame, s2, device, local_rank, False, ordering="strips"))
+
+    def mixed_triangles():
+        # the mixed 64-mesh scene at 100 k instances: commands from 12 to 23 k triangles; the stage launches both of its large-frame
+        # grids and the workgroup-per-command one takes the frame (tri_choice_is_block; always the wave-per-command kernel: 0.71 ms)
+        row = triangle_leg(torch, renderer_amd, scene, make_frame, scene.make_scene(3, n=100_000), device, local_rank, False, config=3)
+        row["note"] = ("mixed scene: the largest commands' walk is longer than a wave's share of the frame, so the workgroup-per-command grid is chosen on "
+                       "the device (profiles/r04_triangle_kernel_choice.txt)")
+        return row
+
+    guarded("triangle_cull_mixed_100k", mixed_triangles)
     guarded("light_draw_lists", lambda: light_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank))
     guarded("culled_views_x4", lambda: views_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank, stream))
     guarded("skinned_256k", lambda: skinned_leg(torch, renderer_amd, scene, make_frame, None, device, local_rank))

@@ -47,6 +47,7 @@ mip::PlanState plan_state(const MipContext* ctx) {
   st.tri_block_threads = ctx->tri_block_threads;
   st.tri_block_max = ctx->tri_block_max;
   st.tri_parts_max = ctx->tri_parts_max;
+  st.tri_no_choice = ctx->tri_no_choice;
   st.max_lod_tris = ctx->max_lod_tris;
   st.n_joints = ctx->n_joints;
   return st;
@@ -313,6 +314,11 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         mip::launch_triangle_cull_block(plan.tri_threads, plan.tri_blocks, stream, t);
       } else {
         if (plan.tri_reset_ticket) MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));  // only the wave-per-command kernel hands out tickets
+        if (plan.tri_either_blocks) {  // both grids; one returns at once (tri_choice_is_block)
+          t.index_total = a.index_total;
+          t.max_lod_tris = ctx->max_lod_tris;
+          mip::launch_triangle_cull_block(256, plan.tri_either_blocks, stream, t);
+        }
         mip::launch_triangle_cull_waves(plan.tri_blocks, stream, t);
       }
       MIP_HIP(ctx, hipGetLastError());

@@ -112,6 +112,7 @@ struct MipContext {
   uint32_t tri_block_threads = 0;  // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
+  bool tri_no_choice = false;      // tuning (MIP_TUNE_TRI_NO_CHOICE): large frames always take the wave-per-command kernel
                                    // measured (DamagedHelmet entry, frame time parts / workgroup-per-command): 30 instances 14 / 24 us,
                                    // 200: 16 / 25, 1000: 41 / 47, 2000: 67 / 64, 4000: 113 / 83
   uint32_t max_lod_tris = 0;       // largest triangle count of LOD 0 / LOD 1 over the mesh table

@@ -31,6 +31,7 @@ struct PlanState {
   uint32_t tri_block_threads = 0;  // MIP_TUNE_TRI_BLOCK_THREADS: 256 | 512 | 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel, 0 = off
+  bool tri_no_choice = false;      // MIP_TUNE_TRI_NO_CHOICE: large frames always take the wave-per-command kernel (A/B)
   uint32_t max_lod_tris = 0;       // largest triangle count of LOD 0 / LOD 1 over the mesh table
   uint32_t n_joints = 0;           // skinned frames
 };
@@ -66,6 +67,8 @@ struct LaunchPlan {
   // row f-1: per-triangle stage behind it
   TriangleKernel tri = TriangleKernel::none;
   uint32_t tri_threads = 0, tri_blocks = 0;
+  uint32_t tri_either_blocks = 0;  // > 0: ALSO launch the 256-thread workgroup-per-command kernel over this grid; the two kernels pick
+                                   // one of themselves on the device from the frame's own totals (triangle_kernels.hpp, tri_choice)
   bool tri_reset_ticket = false;   // the wave-per-command kernel pulls commands from a counter the host zeroes
   Recompact recompact = Recompact::none;
   uint32_t recompact_blocks = 0;
@@ -184,6 +187,11 @@ inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
       uint32_t blocks = (n + 3u) / 4u;
       const uint32_t max_blocks = st.cu_count * 8u;
       p.tri_blocks = blocks > max_blocks ? max_blocks : blocks;
+      // Which of the two is faster depends on the frame, not on the instance count: a wave walks a command alone, so the
+      // launch ends with the largest commands' tails (mixed scene, 100 k instances: 0.72 ms against 0.49 for a workgroup per
+      // command; 400 k: equal; one-mesh scene: the wave kernel 6 % ahead). The totals that decide it are on the device when
+      // the stage starts, so BOTH grids are launched and one of them returns at once (tri_choice).
+      if (!st.tri_no_choice) p.tri_either_blocks = st.cu_count * 8u;
     }
     if (n <= st.tri_block_max) {
       p.recompact = Recompact::single;

@@ -37,6 +37,8 @@ struct TriangleArgs {
   uint32_t* ticket;               // next command to hand out; zeroed by the host before the launch
   uint32_t* final_index_count;    // parts kernel only: where a command's final indexCount goes (see RecompactArgs.index_count)
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
+  const uint32_t* index_total;    // the frame's total indexCount before the stage (device), for tri_choice; null = no choice
+  uint32_t max_lod_tris;          // largest command the mesh table can produce, in triangles
   float pv[16];
 };
 

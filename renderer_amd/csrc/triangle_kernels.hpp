@@ -144,12 +144,25 @@ __device__ __forceinline__ bool model_is_affine(const float (&model)[16], uint32
   return geometry_finite != 0u && model[3] == 0.0f && model[7] == 0.0f && model[11] == 0.0f && model[15] == 1.0f;
 }
 
+// Large frames launch the wave-per-command grid AND a workgroup-per-command grid; every workgroup of both asks this
+// (wave-uniform, two scalar loads) and one grid returns at once. A wave walks its command alone: the launch cannot end
+// before the largest command has been walked by ONE wave, so when that walk is longer than a wave's share of the whole
+// frame (total triangles / the 8 192 waves of the grid) the launch is mostly tail and a workgroup per command — a quarter
+// of the walk, no tickets — wins (measured, profiles/r04_triangle_kernel_choice.txt: mixed scene 100 k instances 0.72 ->
+// 0.49 ms, 200 k 1.04 -> 0.94, 400 k equal; one-mesh scene at 100 k: the wave kernel by 6 %).
+constexpr uint32_t kTriChoiceWaves = 8192;
+__device__ __forceinline__ bool tri_choice_is_block(const TriangleArgs& a) {
+  const unsigned long long total_tris = (unsigned long long)(*a.index_total) / 3ull;
+  return (unsigned long long)a.max_lod_tris * kTriChoiceWaves > total_tris;
+}
+
 #ifndef MIP_TRI_MIN_WAVES_PER_SIMD
 #define MIP_TRI_MIN_WAVES_PER_SIMD 4
 #endif
 
 __global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
+  if (a.index_total && tri_choice_is_block(a)) return;  // this frame is the workgroup-per-command grid's
   const uint32_t count = *a.count;
   float pv[16];
 #pragma unroll
@@ -344,6 +357,7 @@ template <uint32_t kTriBlock>
 __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(const TriangleArgs a) {
   __shared__ uint32_t s_wave[2][kTriBlock / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (a.index_total && !tri_choice_is_block(a)) return;  // this frame is the wave-per-command grid's
   const uint32_t count = *a.count;
   float pv[16];
 #pragma unroll

@@ -85,7 +85,9 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
     } else {
       CHECK(st.n > st.tri_block_max, "wave-per-command only above tri_block_max");
       CHECK(p.tri_blocks <= st.cu_count * 8u && (uint64_t)p.tri_blocks * 4u >= (st.n < st.cu_count * 32u ? st.n : 1u), "waves grid");
+      CHECK(p.tri_either_blocks == (st.tri_no_choice ? 0u : st.cu_count * 8u), "large frames launch both grids unless the choice is tuned off");
     }
+    if (p.tri != TriangleKernel::waves) CHECK(p.tri_either_blocks == 0, "only large frames choose on the device");
     CHECK((p.recompact == Recompact::single) == (st.n <= st.tri_block_max), "one-workgroup re-compaction for small frames");
     if (p.recompact == Recompact::wide) CHECK((uint64_t)p.recompact_blocks * 1024u >= st.n, "wide re-compaction covers the list");
   } else {
@@ -154,7 +156,10 @@ int main() {
           rq.model = rq.cmds = rq.count = rq.triangles = true;
           rq.flags = MIP_OUT_DEVICE;
           rq.cmds_address = 0x1000;
-          check_one(st, rq);
+          for (bool no_choice : {false, true}) {
+            st.tri_no_choice = no_choice;
+            check_one(st, rq);
+          }
         }
   CHECK(plan_wire_index_bits(0) == 31 && plan_wire_index_bits(1) == 31 && plan_wire_index_bits(2) == 30 && plan_wire_index_bits(64) == 25 &&
         plan_wire_index_bits(65) == 24 && plan_wire_index_bits(0xffffffffu) == 0, "index bits of a packed record");

@@ -17,19 +17,21 @@ python3 - <<PY
 import csv, glob, collections, json, hashlib
 out="$OUT"
 acc=collections.defaultdict(list); dur=collections.defaultdict(list)
+# large frames launch two grids and one returns at once (tri_choice_is_block): the counters of the one that did the work
+KERNEL = "${PMC_TRI_KERNEL:-mip_triangle_cull_kernel(}"
 for f in glob.glob(f"{out}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "triangle_cull" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(f"{out}/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "triangle_cull" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 m={k: sum(v)/len(v) for k,v in acc.items()}
 sha=hashlib.sha256(open("$ROOT/renderer_amd/csrc/triangle_kernels.hpp","rb").read()).hexdigest()[:16]
 kern={k: sum(v)/len(v) for k,v in dur.items()}
 doc=dict(triangle_source_sha=sha, config=$CFG, instances=$N, ordering="$ORDERING", library="${MIP_LIBRARY:-product}", counters_per_launch=m, kernel_ns_under_pmc=kern,
-         note="means per launch of mip_triangle_cull*_kernel over the 13 frames tri_bench.py runs; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves")
+         note="means per launch of the wave-per-command kernel (PMC_TRI_KERNEL selects another) over the 13 frames tri_bench.py runs; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves")
 if m.get("SQ_WAVE_CYCLES"):
     doc["fractions_of_wave_cycles"]={k: m[k]/m["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU") if k in m}
 if m.get("TCC_HIT_sum") is not None and (m.get("TCC_HIT_sum",0)+m.get("TCC_MISS_sum",0)):
