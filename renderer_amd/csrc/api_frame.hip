@@ -317,6 +317,8 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         if (plan.tri_either_blocks) {  // both grids; one returns at once (tri_choice_is_block)
           t.index_total = a.index_total;
           t.max_lod_tris = ctx->max_lod_tris;
+          if (const char* env = std::getenv("MIP_TUNE_TRI_CHOICE"))  // A/B: force the device-side choice ("block" | "waves")
+            t.max_lod_tris = env[0] == 'b' ? 0x7fffffffu : 0u;
           mip::launch_triangle_cull_block(256, plan.tri_either_blocks, stream, t);
         }
         mip::launch_triangle_cull_waves(plan.tri_blocks, stream, t);
