@@ -97,6 +97,25 @@ inline LaunchPlan plan_refuse(int32_t status, const char* why) {
   return p;
 }
 
+// Large per-triangle frames launch the wave-per-command AND the workgroup-per-command grid (LaunchPlan.tri_either_blocks); every
+// workgroup of both evaluates THIS on the device, from totals the frame kernel has just written, and one grid returns at once.
+// (constexpr: callable from device code as it stands, and enumerated on the CPU by tests/native/frame_plan_check.cpp.)
+// A wave walks its command alone: the launch cannot end before the largest command has been walked by ONE wave, so when that
+// walk is long against a wave's share of the whole frame (total triangles / the 8 192 waves of the grid) the launch is mostly
+// tail, and a workgroup per command — a quarter of the walk, no tickets, but a barrier per step — wins. Measured
+// (profiles/r04_triangle_kernel_choice.txt), share = largest command / (total / 8 192), spread = largest / mean command:
+//   mixed scene (spread ~10): 100 k instances share 3.3: 0.71 -> 0.47 ms; 200 k 1.6: 1.03 -> 0.88; 400 k 0.8: 1.73 -> 1.62;
+//                             600 k 0.55: 2.43 -> 2.33; 1 M 0.33: equal
+//   one-mesh scene (spread 1.9: every command is near the largest, the tail is only rounding): 70 k share 0.85: the wave
+//                             kernel by 3.5 %; 100 k 0.6: by 6 %; 150 k 0.4: by 12 %
+// Rule: share > 1, or share > 0.5 with spread > 4.
+constexpr uint32_t kPlanTriChoiceWaves = 8192;
+constexpr bool plan_tri_choice_is_block(uint32_t max_lod_tris, uint32_t index_total, uint32_t command_count) {
+  const unsigned long long total_tris = (unsigned long long)index_total / 3ull;
+  const unsigned long long walk = (unsigned long long)max_lod_tris * kPlanTriChoiceWaves;  // share = walk / total_tris
+  return walk > total_tris || (2ull * walk > total_tris && (unsigned long long)max_lod_tris * command_count > 4ull * total_tris);
+}
+
 // The whole decision. Order of the checks = order of the error messages round 3's validate_run produced.
 inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
   if (!st.have_instances || !st.have_meshes) return plan_refuse(MIP_ERR_NOT_READY, "instances or mesh table not set");

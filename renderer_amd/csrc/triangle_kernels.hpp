@@ -3,6 +3,7 @@
 
 #include "instance_kernel.hpp"
 #include "stage_args.hpp"
+#include "frame_plan.hpp"
 
 #pragma clang fp contract(off)
 
@@ -145,22 +146,9 @@ __device__ __forceinline__ bool model_is_affine(const float (&model)[16], uint32
 }
 
 // Large frames launch the wave-per-command grid AND a workgroup-per-command grid; every workgroup of both asks this
-// (wave-uniform, three scalar loads) and one grid returns at once. A wave walks its command alone: the launch cannot end
-// before the largest command has been walked by ONE wave, so when that walk is long against a wave's share of the whole
-// frame (total triangles / the 8 192 waves of the grid) the launch is mostly tail, and a workgroup per command — a quarter
-// of the walk, no tickets, but a barrier per step — wins. Measured (profiles/r04_triangle_kernel_choice.txt), with
-// share = largest command / (total / 8 192) and spread = largest command / mean command:
-//   mixed scene (spread ~10): 100 k instances share 3.3: 0.71 -> 0.47 ms; 200 k 1.6: 1.03 -> 0.88; 400 k 0.8: 1.73 -> 1.62;
-//                             600 k 0.55: 2.43 -> 2.33; 1 M 0.33: equal
-//   one-mesh scene (spread 1.9: every command is near the largest, the tail is only rounding): 70 k share 0.85: the wave
-//                             kernel by 3.5 %; 100 k 0.6: by 6 %; 150 k 0.4: by 12 %
-// Rule: share > 1, or share > 0.5 with spread > 4.
-constexpr uint32_t kTriChoiceWaves = 8192;
+// (wave-uniform, three scalar loads) and one grid returns at once. The rule and its measurements: frame_plan.hpp.
 __device__ __forceinline__ bool tri_choice_is_block(const TriangleArgs& a) {
-  const unsigned long long total_tris = (unsigned long long)(*a.index_total) / 3ull;
-  const unsigned long long walk = (unsigned long long)a.max_lod_tris * kTriChoiceWaves;  // share = walk / total_tris
-  if (walk > total_tris) return true;
-  return 2ull * walk > total_tris && (unsigned long long)a.max_lod_tris * (*a.count) > 4ull * total_tris;
+  return plan_tri_choice_is_block(a.max_lod_tris, *a.index_total, *a.count);
 }
 
 #ifndef MIP_TRI_MIN_WAVES_PER_SIMD

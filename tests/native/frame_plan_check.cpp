@@ -95,7 +95,33 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
   }
 }
 
+// The device-side choice between the two large-frame triangle grids, on the frames it was measured on
+// (profiles/r04_triangle_kernel_choice.txt): {largest command, total indices, commands} -> workgroup-per-command grid?
+static void check_tri_choice() {
+  struct Row { const char* what; uint32_t max_lod_tris, index_total, commands; bool block; };
+  const Row rows[] = {
+      {"mixed 70 k", 23358, 41000000u * 3u, 18220, true},     {"mixed 100 k", 23358, 57600000u * 3u, 25776, true},
+      {"mixed 200 k", 23358, 114400000u * 3u, 51355, true},   {"mixed 400 k", 23358, 229300000u * 3u, 103015, true},
+      {"mixed 600 k", 23358, 343900000u * 3u, 154705, true},  {"mixed 1 M", 23358, 571400000u * 3u, 257864, false},
+      {"one mesh 70 k", 15452, 149500000u * 3u, 18353, false}, {"one mesh 100 k", 15452, 213000000u * 3u, 26154, false},
+      {"one mesh 150 k", 15452, 319000000u * 3u, 39209, false}, {"an empty frame", 15452, 0u, 0u, true},
+      {"one command", 15452, 15452u * 3u, 1u, true}};
+  for (const Row& r : rows)
+    CHECK(plan_tri_choice_is_block(r.max_lod_tris, r.index_total, r.commands) == r.block, "triangle grid choice for %s", r.what);
+  // monotone: more triangles in the frame never turn the wave-per-command choice back into the workgroup one
+  for (uint32_t max_tris : {12u, 1000u, 23358u})
+    for (uint32_t commands : {1u, 1000u, 100000u}) {
+      bool seen_waves = false;
+      for (uint64_t total = 0; total <= 0xffffffffull; total = total * 2 + 3) {
+        const bool block = plan_tri_choice_is_block(max_tris, (uint32_t)total, commands);
+        if (!block) seen_waves = true;
+        CHECK(!(seen_waves && block), "choice not monotone in the frame's total (max %u, %u commands, total %llu)", max_tris, commands, (unsigned long long)total);
+      }
+    }
+}
+
 int main() {
+  check_tri_choice();
   const uint32_t sizes[] = {0u, 1u, 257u, 768u, 1025u, 3073u, 65537u, 917504u, 917505u, 1114112u, 1114113u, 0x3fffffffu};  // both order thresholds at 256 CUs
   const uint32_t flag_sets[] = {MIP_OUT_HOST, MIP_OUT_DEVICE, MIP_OUT_DEVICE | MIP_OUT_ASYNC, MIP_OUT_ASYNC, MIP_OUT_DEVICE | MIP_OUT_WIRE,
                                 MIP_OUT_DEVICE | MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED, MIP_OUT_DEVICE | MIP_OUT_WIRE_PACKED, MIP_OUT_WIRE,
