@@ -808,7 +808,7 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
 
     def mixed_triangles():
         # the mixed 64-mesh scene at 100 k instances: commands from 12 to 23 k triangles; the stage launches both of its large-frame
-        # grids and the workgroup-per-command one takes the frame (tri_choice_is_block; always the wave-per-command kernel: 0.71 ms)
+        # grids and the ticket-pulling workgroup-per-command one takes the frame (plan_tri_choice_is_block; always the wave-per-command kernel: 0.71 ms)
         row = triangle_leg(torch, renderer_amd, scene, make_frame, scene.make_scene(3, n=100_000), device, local_rank, False, config=3)
         row["note"] = ("mixed scene: the largest commands' walk is longer than a wave's share of the frame, so the workgroup-per-command grid is chosen on "
                        "the device (profiles/r04_triangle_kernel_choice.txt)")

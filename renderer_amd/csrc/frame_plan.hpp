@@ -67,6 +67,7 @@ struct LaunchPlan {
   // row f-1: per-triangle stage behind it
   TriangleKernel tri = TriangleKernel::none;
   uint32_t tri_threads = 0, tri_blocks = 0;
+  bool tri_block_tickets = false;  // the workgroup-per-command kernel pulls its commands from the counter (many more commands than workgroups)
   uint32_t tri_either_blocks = 0;  // > 0: ALSO launch the 256-thread workgroup-per-command kernel over this grid; the two kernels pick
                                    // one of themselves on the device from the frame's own totals (triangle_kernels.hpp, tri_choice)
   bool tri_reset_ticket = false;   // the wave-per-command kernel pulls commands from a counter the host zeroes
@@ -104,16 +105,18 @@ inline LaunchPlan plan_refuse(int32_t status, const char* why) {
 // walk is long against a wave's share of the whole frame (total triangles / the 8 192 waves of the grid) the launch is mostly
 // tail, and a workgroup per command — a quarter of the walk, no tickets, but a barrier per step — wins. Measured
 // (profiles/r04_triangle_kernel_choice.txt), share = largest command / (total / 8 192), spread = largest / mean command:
-//   mixed scene (spread ~10): 100 k instances share 3.3: 0.71 -> 0.47 ms; 200 k 1.6: 1.03 -> 0.88; 400 k 0.8: 1.73 -> 1.62;
-//                             600 k 0.55: 2.43 -> 2.33; 1 M 0.33: equal
-//   one-mesh scene (spread 1.9: every command is near the largest, the tail is only rounding): 70 k share 0.85: the wave
-//                             kernel by 3.5 %; 100 k 0.6: by 6 %; 150 k 0.4: by 12 %
-// Rule: share > 1, or share > 0.5 with spread > 4.
+//   (workgroup grid pulling tickets; ms per frame, workgroup-per-command / wave-per-command)
+//   mixed scene (spread ~10): 100 k instances share 3.3: 0.43 / 0.71; 200 k 1.6: 0.75 / 1.03; 400 k 0.8: 1.38 / 1.73;
+//                             1 M 0.33: 3.31 / 3.70
+//   one-mesh scene (spread 1.9: every command is near the largest, the tail is only rounding): 70 k share 0.85: 0.755 / 0.776;
+//                             100 k 0.6: 1.03 / 1.01; 150 k 0.4: 1.42 / 1.40; 300 k 0.2: 2.63 / 2.51
+// Rule: share > 0.7, or spread > 4.
 constexpr uint32_t kPlanTriChoiceWaves = 8192;
+constexpr uint32_t kPlanTriBlockTicketsFrom = 32768;  // instances above which the workgroup-per-command kernel pulls tickets
 constexpr bool plan_tri_choice_is_block(uint32_t max_lod_tris, uint32_t index_total, uint32_t command_count) {
   const unsigned long long total_tris = (unsigned long long)index_total / 3ull;
   const unsigned long long walk = (unsigned long long)max_lod_tris * kPlanTriChoiceWaves;  // share = walk / total_tris
-  return walk > total_tris || (2ull * walk > total_tris && (unsigned long long)max_lod_tris * command_count > 4ull * total_tris);
+  return 10ull * walk > 7ull * total_tris || (unsigned long long)max_lod_tris * command_count > 4ull * total_tris;
 }
 
 // The whole decision. Order of the checks = order of the error messages round 3's validate_run produced.
@@ -199,6 +202,9 @@ inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
       const uint32_t per_cu = 2u * (1024u / p.tri_threads);
       uint32_t blocks = n < st.cu_count * per_cu ? n : st.cu_count * per_cu;
       p.tri_blocks = blocks ? blocks : 1u;
+      // many more commands than workgroups: pulled from the counter, not dealt by a stride (one-mesh scene 20 k instances
+      // 0.24 vs 0.25 ms for the stride, 40 k 0.48 -> 0.45; mixed 60 k 0.34 -> 0.30: profiles/r04_triangle_block_tickets.txt)
+      p.tri_block_tickets = p.tri_reset_ticket = n > kPlanTriBlockTicketsFrom;
     } else {
       p.tri = TriangleKernel::waves;
       p.tri_threads = 256;

@@ -39,6 +39,7 @@ struct TriangleArgs {
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
   const uint32_t* index_total;    // the frame's total indexCount before the stage (device), for tri_choice; null = no choice
   uint32_t max_lod_tris;          // largest command the mesh table can produce, in triangles
+  uint32_t pull_tickets;          // workgroup-per-command kernel: pull commands from `ticket` instead of a static stride
   float pv[16];
 };
 

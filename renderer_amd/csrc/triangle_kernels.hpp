@@ -358,7 +358,20 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
 #pragma unroll
   for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
 
-  for (uint32_t c = blockIdx.x; c < count; c += gridDim.x) {
+  // Many more commands than workgroups (a.pull_tickets, set by the plan): commands are pulled from the counter instead of
+  // dealt by a static stride — a workgroup's 13 commands of a 100 k-instance frame differ by +-18 % in triangles between
+  // workgroups, and the launch waits for the unluckiest (round 4, profiles/r04_triangle_block_tickets.txt: one-mesh scene
+  // 100 k instances 1.08 -> 1.03 ms, mixed 200 k 0.89 -> 0.75, mixed 1 M 3.70 -> 3.31; below ~30 k instances the stride wins).
+  __shared__ uint32_t s_ticket;
+  const bool ticketed = a.pull_tickets != 0u;
+  for (uint32_t c = blockIdx.x, pulled = 0; pulled <= count; c += gridDim.x, ++pulled) {
+    if (ticketed) {
+      __syncthreads();  // everybody has read the previous ticket
+      if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
+      __syncthreads();
+      c = s_ticket;
+    }
+    if (c >= count) break;
     const uint32_t index_count = a.cmds[c * kCmdWords + 0];
     const uint32_t first_index = a.cmds[c * kCmdWords + 2];
     const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];

@@ -74,7 +74,8 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
   if (rq.triangles) {
     CHECK(p.tri_blocks >= 1, "a triangle launch has a grid");
     CHECK(p.need_part_status == (p.tri == TriangleKernel::parts), "granules only for the parts kernel");
-    CHECK(p.tri_reset_ticket == (p.tri == TriangleKernel::waves), "only the wave-per-command kernel pulls from the counter");
+    CHECK(p.tri_reset_ticket == (p.tri == TriangleKernel::waves || p.tri_block_tickets), "the counter is zeroed exactly for the kernels that pull from it");
+    CHECK(p.tri_block_tickets == (p.tri == TriangleKernel::block && st.n > 32768u), "the workgroup kernel pulls tickets when commands far outnumber workgroups");
     if (p.tri == TriangleKernel::parts) {
       CHECK(st.frame_slots == 1 && st.n <= st.tri_parts_max && !st.tri_block_threads && st.max_lod_tris <= 16u * 256u * 8u, "parts kernel preconditions");
       CHECK(p.tri_blocks <= st.cu_count * 4u && p.tri_blocks <= st.n * 16u, "parts grid: resident as a whole, no more blocks than items");
@@ -102,10 +103,10 @@ static void check_tri_choice() {
   const Row rows[] = {
       {"mixed 70 k", 23358, 41000000u * 3u, 18220, true},     {"mixed 100 k", 23358, 57600000u * 3u, 25776, true},
       {"mixed 200 k", 23358, 114400000u * 3u, 51355, true},   {"mixed 400 k", 23358, 229300000u * 3u, 103015, true},
-      {"mixed 600 k", 23358, 343900000u * 3u, 154705, true},  {"mixed 1 M", 23358, 571400000u * 3u, 257864, false},
-      {"one mesh 70 k", 15452, 149500000u * 3u, 18353, false}, {"one mesh 100 k", 15452, 213000000u * 3u, 26154, false},
-      {"one mesh 150 k", 15452, 319000000u * 3u, 39209, false}, {"an empty frame", 15452, 0u, 0u, true},
-      {"one command", 15452, 15452u * 3u, 1u, true}};
+      {"mixed 600 k", 23358, 343900000u * 3u, 154705, true},  {"mixed 1 M", 23358, 571400000u * 3u, 257864, true},
+      {"one mesh 70 k", 15452, 149500000u * 3u, 18353, true}, {"one mesh 100 k", 15452, 213000000u * 3u, 26154, false},
+      {"one mesh 150 k", 15452, 319000000u * 3u, 39209, false}, {"one mesh 300 k", 15452, 638000000u * 3u, 78400, false},
+      {"an empty frame", 15452, 0u, 0u, true},                {"one command", 15452, 15452u * 3u, 1u, true}};
   for (const Row& r : rows)
     CHECK(plan_tri_choice_is_block(r.max_lod_tris, r.index_total, r.commands) == r.block, "triangle grid choice for %s", r.what);
   // monotone: more triangles in the frame never turn the wave-per-command choice back into the workgroup one
