@@ -364,14 +364,22 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
   // 100 k instances 1.08 -> 1.03 ms, mixed 200 k 0.89 -> 0.75, mixed 1 M 3.70 -> 3.31; below ~30 k instances the stride wins).
   __shared__ uint32_t s_ticket;
   const bool ticketed = a.pull_tickets != 0u;
+  // Consecutive commands per ticket: same-address returning atomics are served at ~11 ns each, so a quarter of a million
+  // tickets ARE the launch (mixed scene, 1 M instances, 258 k commands: 3.32 -> 2.81 ms with four commands per ticket;
+  // 400 k: 1.38 -> 1.27; below ~60 k commands single tickets balance better: profiles/r04_triangle_block_tickets.txt)
+  const uint32_t batch = count >= 65536u ? 4u : 1u;
   for (uint32_t c = blockIdx.x, pulled = 0; pulled <= count; c += gridDim.x, ++pulled) {
     if (ticketed) {
-      __syncthreads();  // everybody has read the previous ticket
-      if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
-      __syncthreads();
-      c = s_ticket;
+      if (pulled % batch == 0u) {
+        __syncthreads();  // everybody has read the previous ticket
+        if (tid == 0) s_ticket = atomicAdd(a.ticket, batch);
+        __syncthreads();
+        c = s_ticket;
+      } else {
+        c = c - gridDim.x + 1u;  // the next command of the batch
+      }
     }
-    if (c >= count) break;
+    if (c >= count) { if (ticketed && pulled % batch != batch - 1u) continue; break; }
     const uint32_t index_count = a.cmds[c * kCmdWords + 0];
     const uint32_t first_index = a.cmds[c * kCmdWords + 2];
     const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
