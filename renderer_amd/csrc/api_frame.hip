@@ -312,7 +312,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         mip::launch_triangle_cull_parts(plan.tri_blocks, stream, pa);
       } else if (plan.tri == mip::TriangleKernel::block) {
         if (plan.tri_reset_ticket) MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
-        t.pull_tickets = plan.tri_block_tickets ? 1u : 0u;
+        t.pull_tickets = plan.tri_block_tickets ? ctx->tri_batch_from : 0u;
         mip::launch_triangle_cull_block(plan.tri_threads, plan.tri_blocks, stream, t);
       } else {
         if (plan.tri_reset_ticket) MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));  // only the wave-per-command kernel hands out tickets
@@ -321,7 +321,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
           t.max_lod_tris = ctx->max_lod_tris;
           if (const char* env = std::getenv("MIP_TUNE_TRI_CHOICE"))  // A/B: force the device-side choice ("block" | "waves")
             t.max_lod_tris = env[0] == 'b' ? 0x7fffffffu : 0u;
-          t.pull_tickets = 1u;  // (the wave-per-command kernel ignores it: it always pulls)
+          t.pull_tickets = ctx->tri_batch_from;  // (the wave-per-command kernel ignores it: it always pulls single commands)
           mip::launch_triangle_cull_block(256, plan.tri_either_blocks, stream, t);
         }
         mip::launch_triangle_cull_waves(plan.tri_blocks, stream, t);

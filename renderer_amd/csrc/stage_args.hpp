@@ -39,7 +39,8 @@ struct TriangleArgs {
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
   const uint32_t* index_total;    // the frame's total indexCount before the stage (device), for tri_choice; null = no choice
   uint32_t max_lod_tris;          // largest command the mesh table can produce, in triangles
-  uint32_t pull_tickets;          // workgroup-per-command kernel: pull commands from `ticket` instead of a static stride
+  uint32_t pull_tickets;          // workgroup-per-command kernel: pull commands from `ticket` instead of a static stride: 0 = stride, else the
+                                  // command count from which a ticket is FOUR consecutive commands (65 536; MIP_TUNE_TRI_BATCH_FROM for tests)
   float pv[16];
 };
 

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kTriBlock) void mip_triangle_cull_block_kernel(cons
   // Consecutive commands per ticket: same-address returning atomics are served at ~11 ns each, so a quarter of a million
   // tickets ARE the launch (mixed scene, 1 M instances, 258 k commands: 3.32 -> 2.81 ms with four commands per ticket;
   // 400 k: 1.38 -> 1.27; below ~60 k commands single tickets balance better: profiles/r04_triangle_block_tickets.txt)
-  const uint32_t batch = count >= 65536u ? 4u : 1u;
+  const uint32_t batch = ticketed && count >= a.pull_tickets ? 4u : 1u;
   for (uint32_t c = blockIdx.x, pulled = 0; pulled <= count; c += gridDim.x, ++pulled) {
     if (ticketed) {
       if (pulled % batch == 0u) {

@@ -50,7 +50,8 @@ def _oracle(oracle_mod, s, vertices, indices, pv, capacity, first_instance_base=
     return r, cmds, out
 
 
-@pytest.mark.parametrize("config,n,allvis", [(1, 1024, False), (2, 4000, False), (3, 20_000, False), (3, 3000, True)])
+# (3, 40 000): above 32 768 instances the workgroup-per-command kernel pulls its commands from the ticket counter
+@pytest.mark.parametrize("config,n,allvis", [(1, 1024, False), (2, 4000, False), (3, 20_000, False), (3, 3000, True), (3, 40_000, False)])
 def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     s = ra.scene.make_scene(config, n=n, all_visible=allvis)
     vertices, indices = ra.scene.make_geometry(s["meshes"])
@@ -66,14 +67,23 @@ def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     assert 0 < survivors < int(r["draw_cmds"]["indexCount"].astype(np.int64).sum())  # something was culled, something survived
 
 
-@pytest.mark.parametrize("mode", ["wave", "block256", "block512", "block1024", "parts"])
+@pytest.mark.parametrize("mode", ["wave", "wave_only", "tickets", "tickets_x4", "block256", "block512", "block1024", "parts"])
 def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
-    """The library picks sixteen parts per command, a 256/512/1024-thread workgroup per command or one wave per
-    command by instance count;
-    here each variant is forced (tuning variables, read by mip_create) onto the same mixed scene."""
-    if mode == "wave":
-        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+    """The library picks sixteen parts per command, a 256/512/1024-thread workgroup per command (dealt by a stride, or
+    pulling tickets — one or four commands each) or one wave per command by instance count and, for large frames, on the
+    device from the frame's totals; here each variant is forced (tuning variables, read by mip_create and at launch) onto
+    the same mixed scene."""
+    if mode in ("wave", "wave_only", "tickets", "tickets_x4"):
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")   # the large-frame path: both grids, one chosen on the device ...
         monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "0")
+        if mode == "wave":
+            monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "waves")  # ... forced to the wave-per-command grid
+        elif mode == "wave_only":
+            monkeypatch.setenv("MIP_TUNE_TRI_NO_CHOICE", "1")   # the second grid is not launched at all
+        else:
+            monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "block")  # ... to the ticket-pulling workgroup grid
+            if mode == "tickets_x4":
+                monkeypatch.setenv("MIP_TUNE_TRI_BATCH_FROM", "100")  # four consecutive commands per ticket (default: from 65 536 commands)
     elif mode == "parts":  # 16 work items per command (small frames), forced onto this larger frame
         monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "100000000")
     else:
