@@ -225,6 +225,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_NO_CHOICE")) ctx->tri_no_choice = std::atoi(env) != 0;
+    if (const char* env = std::getenv("MIP_TUNE_TRI_CHOICE")) ctx->tri_force_choice = env[0] == 'b' ? 1 : (env[0] == 'w' ? 2 : 0);
     if (const char* env = std::getenv("MIP_TUNE_TRI_BATCH_FROM")) ctx->tri_batch_from = (uint32_t)std::strtoul(env, nullptr, 10);
     if (ctx->tri_batch_from == 0) ctx->tri_batch_from = 1;
     if (const char* env = std::getenv("MIP_TUNE_ORDER")) {

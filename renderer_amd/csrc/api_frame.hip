@@ -319,8 +319,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         if (plan.tri_either_blocks) {  // both grids; one returns at once (tri_choice_is_block)
           t.index_total = a.index_total;
           t.max_lod_tris = ctx->max_lod_tris;
-          if (const char* env = std::getenv("MIP_TUNE_TRI_CHOICE"))  // A/B: force the device-side choice ("block" | "waves")
-            t.max_lod_tris = env[0] == 'b' ? 0x7fffffffu : 0u;
+          if (ctx->tri_force_choice) t.max_lod_tris = ctx->tri_force_choice == 1 ? 0x7fffffffu : 0u;  // tests / A-B runs
           t.pull_tickets = ctx->tri_batch_from;  // (the wave-per-command kernel ignores it: it always pulls single commands)
           mip::launch_triangle_cull_block(256, plan.tri_either_blocks, stream, t);
         }

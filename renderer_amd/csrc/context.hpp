@@ -113,6 +113,7 @@ struct MipContext {
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
   bool tri_no_choice = false;      // tuning (MIP_TUNE_TRI_NO_CHOICE): large frames always take the wave-per-command kernel
+  int tri_force_choice = 0;        // tuning (MIP_TUNE_TRI_CHOICE=block|waves): 1 / 2 force the device-side choice of the large-frame grid
   uint32_t tri_batch_from = 65536; // commands from which the ticket-pulling workgroup kernel takes four per ticket (MIP_TUNE_TRI_BATCH_FROM: tests)
                                    // measured (DamagedHelmet entry, frame time parts / workgroup-per-command): 30 instances 14 / 24 us,
                                    // 200: 16 / 25, 1000: 41 / 47, 2000: 67 / 64, 4000: 113 / 83
