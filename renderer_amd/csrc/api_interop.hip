@@ -191,6 +191,10 @@ static int32_t enqueue_semaphore_op(MipContext* ctx, MipContext::ExternalSemapho
 // Two threads, because a wait that blocks (the consumer of frame k has not finished) must not keep the signal of frame k
 // from going out — the consumer is waiting for exactly that. The threads sleep on a condition variable while nothing is
 // queued; the signaller spins only while a frame whose signal is queued is on the device.
+// words[0]: the wait word (granted sequence number); words[kSignalWord0 + seq % kSignalRing]: the word signal request `seq` is
+// written to by its stream (a cache line away from the wait word)
+static constexpr unsigned kSignalWord0 = 8, kSignalRing = 32, kSemaphoreWordBytes = (kSignalWord0 + kSignalRing) * 8;
+
 struct MipContext::SemaphoreWorkers {
   struct Request {
     MipContext::ExternalSemaphore* sem;
@@ -241,7 +245,8 @@ static void signaller_main(MipContext::SemaphoreWorkers* w) {
     clock_gettime(CLOCK_MONOTONIC, &t0);
     uint32_t polls = 0;
     bool reached = true;
-    while (__atomic_load_n(&rq.sem->words[1], __ATOMIC_ACQUIRE) < rq.seq) {
+    // (this request's own ring word; entries are reused every kSignalRing requests with larger numbers, never smaller)
+    while (__atomic_load_n(&rq.sem->words[kSignalWord0 + rq.seq % kSignalRing], __ATOMIC_ACQUIRE) != rq.seq) {
       if (w->stop.load(std::memory_order_relaxed)) { reached = false; break; }
       if (++polls < 4096u) continue;  // a frame is tens of microseconds: spin that long ...
       timespec now;
@@ -307,14 +312,30 @@ static int32_t enqueue_drm_semaphore(MipContext* ctx, MipContext::ExternalSemaph
     w->signaller = std::thread(signaller_main, w);
     ctx->semaphore_workers = w;
   }
-  const unsigned long long seq = signal ? ++s->signal_seq : ++s->wait_seq;
+  // The stream operation goes first and the request is queued (and the sequence number committed) only when it was accepted:
+  // a helper thread never waits for a value no stream will write, and a refused wait does not consume the external signal.
+  const unsigned long long seq = (signal ? s->signal_seq : s->wait_seq) + 1;
+  if (signal) {
+    // Every signal request has its OWN word (a ring indexed by its sequence number): with frames in flight the slots' streams
+    // are independent, frame n + 1 may finish before frame n, and one shared word would then show n + 1 to the signaller
+    // polling for n — the consumer would be released into a half-written frame n. At most kSignalRing - 1 requests are
+    // outstanding per context (the queue is one FIFO), so a ring entry is never rewritten before its request has been served.
+    {
+      std::unique_lock<std::mutex> lk(w->m);
+      if (!w->idle.wait_for(lk, std::chrono::nanoseconds(2 * kSemaphoreWaitNs), [&] { return w->signals.size() + (w->signaller_busy ? 1u : 0u) < kSignalRing - 1; }))
+        return fail(ctx, MIP_ERR_TIMEOUT, "%u external-semaphore signals are queued and none has been performed", kSignalRing - 1);
+    }
+    MIP_HIP(ctx, hipStreamWriteValue64(stream, &s->words[kSignalWord0 + seq % kSignalRing], seq, 0));
+    s->signal_seq = seq;
+  } else {
+    MIP_HIP(ctx, hipStreamWaitValue64(stream, &s->words[0], seq, hipStreamWaitValueGte, ~0ull));
+    s->wait_seq = seq;
+  }
   {
     std::lock_guard<std::mutex> lk(w->m);
     (signal ? w->signals : w->waits).push_back({s, value, seq});
   }
   (signal ? w->wake_signaller : w->wake_waiter).notify_one();
-  if (signal) MIP_HIP(ctx, hipStreamWriteValue64(stream, &s->words[1], seq, 0));
-  else MIP_HIP(ctx, hipStreamWaitValue64(stream, &s->words[0], seq, hipStreamWaitValueGte, ~0ull));
   return MIP_OK;
 }
 
@@ -355,11 +376,11 @@ int32_t mip_import_external_semaphore_fd(MipContext* ctx, int32_t fd, uint32_t k
   }
   unsigned long long* words = nullptr;
   if (drm_handle && stream_values_usable(ctx)) {  // two pinned, device-visible sequence words (stream-value hand-over)
-    if (hipHostMalloc((void**)&words, 64, hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc((void**)&words, kSemaphoreWordBytes, hipHostMallocMapped) != hipSuccess) {
       (void)hipGetLastError();
       words = nullptr;  // fall back to host functions for this semaphore
     } else {
-      std::memset(words, 0, 64);
+      std::memset(words, 0, kSemaphoreWordBytes);
     }
   }
   auto* entry = new (std::nothrow) MipContext::ExternalSemaphore{sem, kind, drm_handle, words, 0ull, 0ull};

@@ -340,7 +340,7 @@ if rank == 0:
 else:
     t0 = time.time()
     while not os.path.exists(id_path):
-        assert time.time() - t0 < 60
+        assert time.time() - t0 < 900, 'rank 0 never wrote the communicator id (a rendezvous guard, far above any start-up time)'
         time.sleep(0.01)
     uid = open(id_path, "rb").read()
 dev = torch.device("cuda", 0)

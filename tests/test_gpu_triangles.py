@@ -221,7 +221,6 @@ def test_parts_kernel_does_not_depend_on_who_runs_when(oracle_mod, fault):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "renderer_amd", "csrc"), "-s", "dbg"])
     code = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
