@@ -122,6 +122,10 @@ void free_all(MipContext* ctx) {
     (void)hipFree(sl.d_tmp_blocks);
     (void)hipFree(sl.d_tmp_final);
     (void)hipFree(sl.d_part_status);
+    (void)hipFree(sl.d_tri_order);
+    (void)hipFree(sl.d_tri_sort);
+    (void)hipFree(sl.d_chunk_first);
+    (void)hipFree(sl.d_chunk_status);
     (void)hipFree(sl.d_skin_box);
     (void)hipFree(sl.d_frame_ring);
     if (sl.h_frame_stage) (void)hipHostFree(sl.h_frame_stage);
@@ -224,6 +228,11 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_TRI_RANGE_SLOTS")) {
+      const uint32_t v = (uint32_t)std::strtoul(env, nullptr, 10) / 64u * 64u;
+      if (v >= 256u && v <= 8192u) ctx->tri_ticket_slots = v;
+    }
+    if (const char* env = std::getenv("MIP_TUNE_TRI_CHUNKS_FROM")) ctx->tri_chunks_from = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_NO_CHOICE")) ctx->tri_no_choice = std::atoi(env) != 0;
     if (const char* env = std::getenv("MIP_TUNE_TRI_CHOICE")) ctx->tri_force_choice = env[0] == 'b' ? 1 : (env[0] == 'w' ? 2 : 0);
     if (const char* env = std::getenv("MIP_TUNE_TRI_BATCH_FROM")) ctx->tri_batch_from = (uint32_t)std::strtoul(env, nullptr, 10);

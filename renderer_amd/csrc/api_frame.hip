@@ -47,6 +47,8 @@ mip::PlanState plan_state(const MipContext* ctx) {
   st.tri_block_threads = ctx->tri_block_threads;
   st.tri_block_max = ctx->tri_block_max;
   st.tri_parts_max = ctx->tri_parts_max;
+  st.tri_chunks_from = ctx->tri_chunks_from;
+  st.tri_chunk_blocks_per_cu = mip::triangle_chunks_blocks_per_cu();
   st.tri_no_choice = ctx->tri_no_choice;
   st.max_lod_tris = ctx->max_lod_tris;
   st.n_joints = ctx->n_joints;
@@ -289,7 +291,75 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       t.ticket = sl.d_scalars + 3;
       t.geometry_finite = ctx->geometry_finite ? 1u : 0u;
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
-      if (plan.tri == mip::TriangleKernel::parts) {
+      if (plan.tri == mip::TriangleKernel::chunks || plan.tri == mip::TriangleKernel::sorted) {
+        const bool either = plan.tri == mip::TriangleKernel::sorted;  // both grids are launched and one returns at once (tri_not_this_grid)
+        t.first_index_base = frame->first_index_base;
+        t.max_lod_tris = ctx->max_lod_tris;
+        if (ctx->tri_force_choice) t.max_lod_tris = ctx->tri_force_choice == 1 ? 0x7fffffffu : 0u;  // tests / A-B runs: ranges | waves
+        t.choice_waves = plan.tri_blocks * 4u;
+        // ranges of the triangle stream: one per wave of the grid while that keeps them short, else ranges of tri_ticket_slots.
+        // Their number is bounded by the index buffer (a command that does not fit is reported, not walked past it), by what
+        // 32-bit firstIndex can number, and by the largest command times the instances.
+        unsigned long long tris = out->culled_index_capacity / 3ull;
+        if (tris > 0xffffffffull / 3ull) tris = 0xffffffffull / 3ull;
+        if (tris > (unsigned long long)n * ctx->max_lod_tris) tris = (unsigned long long)n * ctx->max_lod_tris;
+        size_t need = (size_t)(tris / ctx->tri_ticket_slots) + 2;
+        if (need < (size_t)plan.tri_blocks * 4u + 1u) need = (size_t)plan.tri_blocks * 4u + 1u;
+        if (sl.chunks_cap < need) {
+          if (sl.d_chunk_first) {  // a frame of this slot may still read the old arrays
+            MIP_HIP(ctx, hipStreamSynchronize(stream));
+            MIP_HIP(ctx, hipFree(sl.d_chunk_first));
+            MIP_HIP(ctx, hipFree(sl.d_chunk_status));
+            sl.d_chunk_first = nullptr; sl.d_chunk_status = nullptr; sl.chunks_cap = 0;
+          }
+          MIP_HIP(ctx, hipMalloc(&sl.d_chunk_first, need * 4));
+          MIP_HIP(ctx, hipMalloc(&sl.d_chunk_status, need * 8));
+          MIP_HIP(ctx, hipMemsetAsync(sl.d_chunk_status, 0, need * 8, stream));
+          sl.chunks_cap = need;
+          sl.chunk_epoch = 0;
+        }
+        if (sl.chunk_epoch == 0xffffffffu) {  // tag wrap: start over on a cleared array
+          MIP_HIP(ctx, hipMemsetAsync(sl.d_chunk_status, 0, sl.chunks_cap * 8, stream));
+          sl.chunk_epoch = 0;
+        }
+        if (either) {
+          // the commands by descending size class for the wave-per-command grid; one clear covers histogram, arrival counter and ticket
+          if (!sl.d_tri_order) MIP_HIP(ctx, hipMalloc(&sl.d_tri_order, cap * 4));
+          if (!sl.d_tri_sort) MIP_HIP(ctx, hipMalloc(&sl.d_tri_sort, mip::kSortWords * 4));
+          MIP_HIP(ctx, hipMemsetAsync(sl.d_tri_sort, 0, mip::kSortWords * 4, stream));
+          t.sort_info = sl.d_tri_sort;
+          t.ticket = sl.d_tri_sort + mip::kSortTicket;
+          t.final_index_count = sl.d_tmp_final;
+          mip::TriangleArgs w = t;
+          w.choice_mode = 2u;
+          w.order = sl.d_tri_order;
+          mip::launch_triangle_sort(plan.tri_map_blocks, stream, w, sl.d_tri_order);
+        } else {
+          MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
+        }
+        mip::TriangleChunkArgs ca{};
+        ca.t = t;
+        ca.t.choice_mode = either ? 1u : 0u;
+        ca.t.final_index_count = sl.d_tmp_final;
+        ca.range_first_cmd = sl.d_chunk_first;
+        ca.range_status = sl.d_chunk_status;
+        ca.ranges_cap = (uint32_t)sl.chunks_cap;
+        ca.n_waves = plan.tri_blocks * 4u;
+        ca.ticket_slots = ctx->tri_ticket_slots;
+        ca.epoch = ++sl.chunk_epoch;
+        ca.first_index_base = frame->first_index_base;
+#ifdef MIP_DEBUG_STAMPS
+        if (const char* env = std::getenv("MIP_DEBUG_TILE_ORDER")) ca.debug_reverse = std::strcmp(env, "reverse") == 0 ? 1u : 0u;
+        if (const char* env = std::getenv("MIP_DEBUG_SKIP_PART")) ca.debug_skip_part = (uint32_t)std::atoi(env) % 16u + 1u;
+#endif
+        mip::launch_triangle_cull_chunks(plan.tri_map_blocks, plan.tri_blocks, stream, ca);
+        if (either) {
+          mip::TriangleArgs w = t;
+          w.choice_mode = 2u;
+          w.order = sl.d_tri_order;
+          mip::launch_triangle_cull_waves(plan.tri_wave_blocks, stream, w);
+        }
+      } else if (plan.tri == mip::TriangleKernel::parts) {
         const size_t cap_cmds = ctx->max_instances < ctx->tri_parts_max ? cap : ctx->tri_parts_max;
         if (!sl.d_part_status) {
           MIP_HIP(ctx, hipMalloc(&sl.d_part_status, cap_cmds * mip::kTriParts * 8));
@@ -328,10 +398,12 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       MIP_HIP(ctx, hipGetLastError());
       // (re-compacting inside the workgroup kernels, by the last workgroup to finish, was measured: the
       // agent-scope fences it needs cost more than the launch they save — 1 k instances 65 vs 49 us)
+      // (the parts and the chunk kernel leave a command's final indexCount beside it: their work items still need the original)
+      const bool final_beside = plan.tri == mip::TriangleKernel::parts || plan.tri == mip::TriangleKernel::chunks || plan.tri == mip::TriangleKernel::sorted;
       if (plan.recompact == mip::Recompact::single) {
         mip::RecompactArgs r{};
         r.in_cmds = sl.d_tmp_cmds;
-        r.index_count = plan.tri == mip::TriangleKernel::parts ? sl.d_tmp_final : nullptr;
+        r.index_count = final_beside ? sl.d_tmp_final : nullptr;
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;
@@ -339,7 +411,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       } else {
         mip::RecompactWideArgs r{};
         r.in_cmds = sl.d_tmp_cmds;
-        r.index_count = plan.tri == mip::TriangleKernel::parts ? sl.d_tmp_final : nullptr;
+        r.index_count = final_beside ? sl.d_tmp_final : nullptr;
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;

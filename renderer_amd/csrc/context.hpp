@@ -43,6 +43,12 @@ struct MipContext {
     uint32_t* d_tmp_final = nullptr;         //                     parts kernel: each command's final indexCount (never written into the command)
     unsigned long long* d_part_status = nullptr;  //                small frames: one granule per (command, part)
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
+    uint32_t* d_chunk_first = nullptr;       // range kernel (round 5): first command of every range of the triangle stream
+    unsigned long long* d_chunk_status = nullptr;  //                   one granule per range
+    size_t chunks_cap = 0;                   //                         ranges both arrays hold
+    uint32_t chunk_epoch = 0;                //                         tag of the last range launch on this slot
+    uint32_t* d_tri_order = nullptr;         // large frames: command numbers by descending size class
+    uint32_t* d_tri_sort = nullptr;          //               kSortWords words: histogram, positions, tickets (triangle_kernels.hpp)
     float* d_skin_box = nullptr;             // skinned frames: per instance posed mesh-space box {min xyz, -, max xyz, -}
     // recorded launches (mip_run_many): the frames of one replay, read by the kernels (KernelArgs.frame_ring),
     // refreshed before every replay from one of two pinned staging halves
@@ -112,6 +118,8 @@ struct MipContext {
   uint32_t tri_block_threads = 0;  // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
+  uint32_t tri_ticket_slots = 4096; // long triangle streams: slots per range of the range kernel (MIP_TUNE_TRI_RANGE_SLOTS: 256 .. 8192, whole steps of 64)
+  uint32_t tri_chunks_from = 0;    // instance counts from this use the range kernel; MIP_TUNE_TRI_CHUNKS_FROM (4294967295 = never: the round-4 kernels)
   bool tri_no_choice = false;      // tuning (MIP_TUNE_TRI_NO_CHOICE): large frames always take the wave-per-command kernel
   int tri_force_choice = 0;        // tuning (MIP_TUNE_TRI_CHOICE=block|waves): 1 / 2 force the device-side choice of the large-frame grid
   uint32_t tri_batch_from = 65536; // commands from which the ticket-pulling workgroup kernel takes four per ticket (MIP_TUNE_TRI_BATCH_FROM: tests)

@@ -31,6 +31,8 @@ struct PlanState {
   uint32_t tri_block_threads = 0;  // MIP_TUNE_TRI_BLOCK_THREADS: 256 | 512 | 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel, 0 = off
+  uint32_t tri_chunks_from = 0;    // instance counts from this use the chunk kernel (round 5); 0xffffffff = never (MIP_TUNE_TRI_CHUNKS_FROM)
+  uint32_t tri_chunk_blocks_per_cu = 8;  // workgroups of the chunk kernel a CU holds at once (asked of the runtime)
   bool tri_no_choice = false;      // MIP_TUNE_TRI_NO_CHOICE: large frames always take the wave-per-command kernel (A/B)
   uint32_t max_lod_tris = 0;       // largest triangle count of LOD 0 / LOD 1 over the mesh table
   uint32_t n_joints = 0;           // skinned frames
@@ -45,7 +47,7 @@ struct PlanRequest {
   uintptr_t cmds_address = 0;      // draw_cmds as an integer (alignment rules of the wire forms)
 };
 
-enum class TriangleKernel : uint8_t { none, parts, block, waves };
+enum class TriangleKernel : uint8_t { none, parts, block, waves, chunks, sorted };
 enum class Recompact : uint8_t { none, single, wide };
 
 struct LaunchPlan {
@@ -67,6 +69,8 @@ struct LaunchPlan {
   // row f-1: per-triangle stage behind it
   TriangleKernel tri = TriangleKernel::none;
   uint32_t tri_threads = 0, tri_blocks = 0;
+  uint32_t tri_map_blocks = 0;     // range kernel: grid of the range-map kernel in front of it (one thread per command); the sort kernels' grid too
+  uint32_t tri_wave_blocks = 0;    // TriangleKernel::sorted: grid of the wave-per-command kernel (tri_blocks is the range kernel's)
   bool tri_block_tickets = false;  // the workgroup-per-command kernel pulls its commands from the counter (many more commands than workgroups)
   uint32_t tri_either_blocks = 0;  // > 0: ALSO launch the 256-thread workgroup-per-command kernel over this grid; the two kernels pick
                                    // one of themselves on the device from the frame's own totals (triangle_kernels.hpp, tri_choice)
@@ -77,6 +81,7 @@ struct LaunchPlan {
   bool need_staging = false;       // host outputs: device staging + copy-back
   bool need_tri_scratch = false;   // list before re-compaction, source offsets, block counts
   bool need_part_status = false;   // granules of the parts kernel
+  bool need_chunk_scratch = false; // chunk map + granules of the chunk kernel
   bool need_skin_box = false;      // per-instance posed box
 };
 
@@ -111,6 +116,18 @@ inline LaunchPlan plan_refuse(int32_t status, const char* why) {
 //   one-mesh scene (spread 1.9: every command is near the largest, the tail is only rounding): 70 k share 0.85: 0.755 / 0.776;
 //                             100 k 0.6: 1.03 / 1.01; 150 k 0.4: 1.42 / 1.40; 300 k 0.2: 2.63 / 2.51
 // Rule: share > 0.7, or spread > 4.
+// Round 5, frames above tri_block_max instances: the wave-per-command kernel takes its commands by size class, largest first, and
+// asks for issue priority while it has walked few of them (triangle_kernels.hpp), so what is left against it is a frame whose largest
+// command is long against a wave's share of the whole frame (share = largest command x waves / triangles of the frame) AND far above
+// the mean command (spread = largest x commands / triangles): then the range kernel, which cuts commands, takes it. Measured
+// (profiles/r05_triangle_stage_modes.txt; ms per frame, range kernel / sorted wave-per-command kernel):
+//   mixed scene (spread ~10): 70 k instances share 4.7: 0.295 / 0.401; 100 k 3.3: 0.395 / 0.454; 200 k 1.6: 0.699 / 0.767;
+//                             400 k 0.8: 1.263 / 1.267; 1 M 0.33: 2.86 / 2.68
+//   one-mesh scene (spread 1.9): 70 k share 0.85: 0.809 / 0.767; 100 k 0.6: 1.106 / 1.003; 300 k 0.2: 2.91 / 2.56
+// Rule: share > 0.7 and spread > 3. Evaluated on the device by both grids (from the slot's own command list); one returns at once.
+constexpr bool plan_tri_choice_is_ranges(uint32_t max_lod_tris, uint32_t total_tris, uint32_t command_count, uint32_t n_waves) {
+  return 10ull * max_lod_tris * n_waves > 7ull * total_tris && (unsigned long long)max_lod_tris * command_count > 3ull * total_tris;
+}
 constexpr uint32_t kPlanTriChoiceWaves = 8192;
 constexpr uint32_t kPlanTriBlockTicketsFrom = 32768;  // instances above which the workgroup-per-command kernel pulls tickets
 constexpr bool plan_tri_choice_is_block(uint32_t max_lod_tris, uint32_t index_total, uint32_t command_count) {
@@ -189,7 +206,17 @@ inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
     //  - above: one wave per command (100 k: 1.15 vs 1.21 ms), commands pulled from a counter.
     const bool parts = st.tri_parts_max && n <= st.tri_parts_max && !st.tri_block_threads && st.frame_slots == 1 &&
                        st.max_lod_tris <= kPlanTriParts * 256u * kPlanTriPartMaxT;
-    if (parts) {
+    if (n >= st.tri_chunks_from && !st.tri_block_threads) {
+      // round 5: equal ranges of the triangle stream, one wave each (triangle_kernels.hpp); frames above tri_block_max instances
+      // ALSO launch the wave-per-command kernel over commands sorted by size class, and one of the two returns at once
+      p.tri = n <= st.tri_block_max ? TriangleKernel::chunks : TriangleKernel::sorted;
+      p.tri_threads = 256;
+      p.need_chunk_scratch = true;
+      p.tri_reset_ticket = true;  // long streams: a wave's later ranges are pulled from the counter (and the sorted commands are)
+      p.tri_map_blocks = (n + 255u) / 256u;
+      p.tri_blocks = st.cu_count * st.tri_chunk_blocks_per_cu;  // resident as a whole: a range's predecessors are running when it looks for them
+      if (p.tri == TriangleKernel::sorted) p.tri_wave_blocks = st.cu_count * 8u;
+    } else if (parts) {
       p.tri = TriangleKernel::parts;
       p.tri_threads = 256;
       p.need_part_status = true;

@@ -39,6 +39,12 @@ struct TriangleArgs {
   uint32_t geometry_finite;       // every position passed to mip_set_geometry was finite
   const uint32_t* index_total;    // the frame's total indexCount before the stage (device), for tri_choice; null = no choice
   uint32_t max_lod_tris;          // largest command the mesh table can produce, in triangles
+  // round 5, large frames: commands handed out LARGEST FIRST (sort kernels below) and a device-side choice between this grid and the range kernel's
+  const uint32_t* order;          // command numbers by descending size class, or null: list order
+  uint32_t* sort_info;            // kSortWords words (layout: triangle_kernels.hpp), zeroed by the host per frame; holds the ticket counter too
+  uint32_t first_index_base;      // MipFrame.first_index_base (the length of the triangle stream is taken from the last command)
+  uint32_t choice_waves;          // waves of the range kernel's grid: the choice rule's measure of the machine
+  uint32_t choice_mode;           // 0 = run; 1 = run iff the frame is the range kernel's; 2 = run iff it is the wave-per-command kernel's
   uint32_t pull_tickets;          // workgroup-per-command kernel: pull commands from `ticket` instead of a static stride: 0 = stride, else the
                                   // command count from which a ticket is FOUR consecutive commands (65 536; MIP_TUNE_TRI_BATCH_FROM for tests)
   float pv[16];
@@ -78,7 +84,37 @@ struct TrianglePartsArgs {
 #endif
 };
 
+// Round 5: the stage as equal RANGES of the frame's triangle stream, one per wave (triangle_kernels.hpp, mip_triangle_cull_ranges_kernel).
+struct TriangleChunkArgs {
+  TriangleArgs t;                      // (index_total, max_lod_tris, pull_tickets unused; ticket: zeroed by the host)
+  uint32_t* range_first_cmd;           // [ranges_cap]: the first command that owns a slot at or behind the range's first slot
+  unsigned long long* range_status;    // [ranges_cap] granules {epoch : 32 | survivors of the range's LAST segment : 32}
+  uint32_t ranges_cap;
+  uint32_t n_waves;                    // waves of the grid the stage is launched over (= 4 * workgroups)
+  uint32_t ticket_slots;               // slots per range of a long stream (a wave's first range dealt statically, the others pulled from the counter)
+  uint32_t epoch;                      // unique per launch on this frame slot, never 0
+  uint32_t first_index_base;           // MipFrame.first_index_base: firstIndex - base is the running sum the slots are numbered by
+#ifdef MIP_DEBUG_STAMPS
+  uint32_t debug_reverse;              // diagnostic build only: ranges are dealt from the LAST one down
+  uint32_t debug_skip_part;            // diagnostic build only: ranges b with b % 16 == value - 1 never publish (0 = off)
+#endif
+};
+
+constexpr uint32_t kSortWords = 256;
+// Layout of TriangleArgs.sort_info (kSortWords words, zeroed by the host per frame). Size class k = floor(log2(triangles)).
+constexpr uint32_t kSortHist = 0;      // [32] commands per size class
+constexpr uint32_t kSortCursor = 32;   // [32] by class: where the next command of the class goes in `order`
+constexpr uint32_t kSortStart = 64;    // [32] by RANK d (d = 0: the largest class): first position of the class in `order`
+constexpr uint32_t kSortTickets = 96;  // [32] by rank: tickets up to and including the class
+constexpr uint32_t kSortBatch = 128;   // [32] by rank: commands per ticket
+constexpr uint32_t kSortDone = 160;    // workgroups of the count kernel that have added their histogram
+constexpr uint32_t kSortTicket = 161;  // the ticket counter of the stage
+static_assert(kSortTicket < kSortWords, "sort_info layout");
+
 // Launchers (defined in stages_tu.hip). Each enqueues one kernel on `stream`; errors surface through hipGetLastError.
+void launch_triangle_sort(uint32_t blocks, hipStream_t stream, const TriangleArgs& a, uint32_t* order);  // size classes: count + prefix, scatter
+uint32_t triangle_chunks_blocks_per_cu();  // workgroups of the range kernel a CU holds at once: its ranges are dealt over a grid that is resident as a whole
+void launch_triangle_cull_chunks(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a);  // range map, then the stage
 void launch_triangle_cull_waves(uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
 void launch_triangle_cull_block(uint32_t threads /* 256 | 512 | 1024 */, uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
 void launch_triangle_cull_parts(uint32_t blocks, hipStream_t stream, const TrianglePartsArgs& a);

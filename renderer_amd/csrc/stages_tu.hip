@@ -1,6 +1,9 @@
 // stages_tu.hip — the library's second translation unit: the kernels that are faster without the SLP vectoriser
 // (per-triangle stage, multi-view cull, shadow-pass lists, skinning, the commands-first frame kernel) and their
 // launchers. Built with the library's floating-point flags PLUS -fno-slp-vectorize (stage_args.hpp has the numbers).
+#include <cstdio>
+#include <cstdlib>
+
 #include "triangle_kernels.hpp"
 #include "light_lists_kernel.hpp"
 #include "skinning_kernel.hpp"
@@ -9,6 +12,16 @@
 namespace mip {
 
 void launch_triangle_cull_waves(uint32_t blocks, hipStream_t stream, const TriangleArgs& a) {
+  static bool said = false;
+  if (!said && std::getenv("MIP_TUNE_VERBOSE")) {
+    said = true;
+    int v = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, mip_triangle_cull_kernel, 256, 0);
+    hipFuncAttributes fa{};
+    (void)hipFuncGetAttributes(&fa, (const void*)mip_triangle_cull_kernel);
+    fprintf(stderr, "mip: wave-per-command kernel: %d workgroups per CU by the runtime's count; %d registers, %zu B LDS, %zu B scratch; grid %u\n", v, fa.numRegs,
+            fa.sharedSizeBytes, fa.localSizeBytes, blocks);
+  }
   hipLaunchKernelGGL(mip_triangle_cull_kernel, dim3(blocks), dim3(256), 0, stream, a);
 }
 
@@ -20,6 +33,35 @@ void launch_triangle_cull_block(uint32_t threads, uint32_t blocks, hipStream_t s
 
 void launch_triangle_cull_parts(uint32_t blocks, hipStream_t stream, const TrianglePartsArgs& a) {
   hipLaunchKernelGGL(mip_triangle_cull_parts_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+uint32_t triangle_chunks_blocks_per_cu() {
+  static int per_cu = 0;  // (one device kind per process: gfx950)
+  if (per_cu <= 0) {
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, mip_triangle_cull_ranges_kernel, 256, 0) != hipSuccess || v < 1) {
+      (void)hipGetLastError();
+      v = 4;
+    }
+    if (v > 8) v = 8;
+    if (const char* env = std::getenv("MIP_TUNE_TRI_RANGE_BLOCKS_PER_CU")) {  // A/B runs
+      const int forced = std::atoi(env);
+      if (forced >= 1 && forced <= 8) v = forced;
+    }
+    if (std::getenv("MIP_TUNE_VERBOSE")) fprintf(stderr, "mip: range kernel: %d workgroups per CU\n", v);
+    per_cu = v;
+  }
+  return (uint32_t)per_cu;
+}
+
+void launch_triangle_cull_chunks(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a) {
+  hipLaunchKernelGGL(mip_triangle_range_map_kernel, dim3(map_blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(mip_triangle_cull_ranges_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+void launch_triangle_sort(uint32_t blocks, hipStream_t stream, const TriangleArgs& a, uint32_t* order) {
+  hipLaunchKernelGGL(mip_triangle_sort_count_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(mip_triangle_sort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, a, order);
 }
 
 void launch_recompact(hipStream_t stream, const RecompactArgs& a) {

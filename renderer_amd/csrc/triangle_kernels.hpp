@@ -145,6 +145,110 @@ __device__ __forceinline__ bool model_is_affine(const float (&model)[16], uint32
   return geometry_finite != 0u && model[3] == 0.0f && model[7] == 0.0f && model[11] == 0.0f && model[15] == 1.0f;
 }
 
+// ---- one command as the walking kernels see it, and the walk itself ----
+struct ChunkCmd {  // one command as a range sees it (wave-uniform)
+  uint32_t index_count, first_index, instance, src_tri, n_tris, slot0;
+  int32_t vertex_offset;
+};
+
+// (The kernel stores through other pointers, so the compiler cannot prove these wave-uniform loads unclobbered and issues
+// them as vector loads; readfirstlane at least returns the words to scalar registers — seven VGPRs per command in flight otherwise.)
+__device__ __forceinline__ uint32_t uniform_word(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uniform_word(float v) { return __uint_as_float(uniform_word(__float_as_uint(v))); }
+
+__device__ __forceinline__ ChunkCmd chunk_load_cmd(const TriangleArgs& a, uint32_t base, uint32_t c) {
+  ChunkCmd m;
+  m.index_count = uniform_word(a.cmds[c * kCmdWords + 0]);
+  m.first_index = uniform_word(a.cmds[c * kCmdWords + 2]);
+  m.vertex_offset = (int32_t)uniform_word(a.cmds[c * kCmdWords + 3]);
+  m.instance = uniform_word(a.cmds[c * kCmdWords + 4]) - a.first_instance_base;
+  m.src_tri = uniform_word(a.src_index_offset[c]) / 3u;
+  m.n_tris = m.index_count / 3u;
+  m.slot0 = (m.first_index - base) / 3u;
+  return m;
+}
+
+__device__ __forceinline__ void chunk_load_model(const TriangleArgs& a, uint32_t instance, float (&model)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 col = a.model[(size_t)instance * 4 + q];
+    model[q * 4 + 0] = uniform_word(col.x); model[q * 4 + 1] = uniform_word(col.y); model[q * 4 + 2] = uniform_word(col.z); model[q * 4 + 3] = uniform_word(col.w);
+  }
+}
+
+// Triangles [t_begin, t_end) of command m, 64 per step.
+//   kDirect   survivors go straight to their place (dst_tri + running count), as in the wave-per-command kernel;
+//   !kDirect  nothing is written yet: the step's 64-bit keep mask goes to masks[step].
+// Returns the survivors.
+// The step is a software pipeline with NO conditional memory operation in it — the wait counter is in order, and the
+// compiler has to assume that a load or store inside a branch may not have been issued, so it waits for everything that
+// is older (round 4's loop waited for the store it had issued a moment ago, and for the next step's indices, before it
+// touched the first vertex):
+//   gathers of step k  ->  store of step k-1  ->  index triple of step k+1  ->  wait for the gathers only  ->  test k.
+// The store goes through a buffer descriptor over the command's own region of the stream: a lane without a survivor
+// gets an offset beyond it and is dropped by the hardware (no branch); a command that does not fit the index buffer gets
+// an empty region. The index prefetch of the last step re-reads that step's own triple (in bounds, never used).
+typedef unsigned int tri_u32x3 __attribute__((ext_vector_type(3)));
+constexpr uint32_t kTriRegionMax = 0x7ffffff0u;   // bytes a region descriptor spans at most (a command of 178 M triangles)
+constexpr uint32_t kTriDropOffset = 0x80000000u;  // beyond every region: the store is dropped
+#ifndef MIP_TRI_STORE_AUX
+#define MIP_TRI_STORE_AUX 0
+#endif
+
+template <bool kAffine, bool kDirect>
+__device__ __forceinline__ uint32_t chunk_walk(const TriangleArgs& a, const ChunkCmd& m, const float (&model)[16], const float (&pv)[16],
+                                               uint32_t t_begin, uint32_t t_end, bool fits, size_t dst_tri, unsigned long long* masks, uint32_t lane) {
+  const uint32_t* tri_indices = a.indices + (size_t)m.src_tri * 3;
+  const unsigned long long region = (unsigned long long)(t_end - t_begin) * 12ull;
+  const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.out_indices + dst_tri * 3, 0,
+      (int)(kDirect && fits ? (region < kTriRegionMax ? (uint32_t)region : kTriRegionMax) : 0u), 0x00020000);
+  uint32_t survivors = 0, step = 0;
+  uint32_t n0, n1, n2;  // idle lanes re-read the segment's last triangle: in bounds
+  {
+    const uint32_t tn = t_begin + lane < t_end ? t_begin + lane : t_end - 1u;
+    const uint32_t* ip = tri_indices + (size_t)tn * 3;
+    n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+  }
+  tri_u32x3 q = {0u, 0u, 0u};          // the previous step's survivors, stored behind this step's gathers
+  uint32_t q_offset = kTriDropOffset;
+  for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u, ++step) {
+    const uint32_t t = t0 + lane;
+    const bool valid = t < t_end;
+    const uint32_t i0 = n0, i1 = n1, i2 = n2;
+    float v[9];
+    triangle_fetch(a.vertices, (long long)m.vertex_offset, i0, i1, i2, v);
+    if constexpr (kDirect) __builtin_amdgcn_raw_buffer_store_b96(q, out, (int)q_offset, 0, MIP_TRI_STORE_AUX);
+    {
+      const uint32_t tn = t + 64u < t_end ? t + 64u : t_end - 1u;
+      const uint32_t* ip = tri_indices + (size_t)tn * 3;
+      n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
+    }
+    const bool keep = !triangle_test<kAffine>(model, pv, v) && valid;
+    const unsigned long long mask = __ballot(keep);
+    if constexpr (kDirect) {
+      q = tri_u32x3{i0, i1, i2};
+      q_offset = keep ? (survivors + lanes_below(mask)) * 12u : kTriDropOffset;
+    } else {
+      if (lane == 0u) masks[step] = mask;  // (the range kernel sizes the buffer for its longest range)
+    }
+    survivors += (uint32_t)__popcll(mask);
+  }
+  if constexpr (kDirect) __builtin_amdgcn_raw_buffer_store_b96(q, out, (int)q_offset, 0, MIP_TRI_STORE_AUX);
+  return survivors;
+}
+
+// Round 5, frames above tri_block_max instances: the range kernel's grid (choice_mode 1) and the wave-per-command grid over the
+// sorted commands (choice_mode 2) are both launched; every workgroup of both — and of the sort and map kernels in front of them
+// — asks this (wave-uniform, from the slot's own command list), and the grid the frame is not for returns at once.
+__device__ __forceinline__ uint32_t stream_slots(const TriangleArgs& a, uint32_t base, uint32_t count) {
+  return (a.cmds[(count - 1u) * kCmdWords + 2] - base) / 3u + a.cmds[(count - 1u) * kCmdWords + 0] / 3u;
+}
+__device__ __forceinline__ bool tri_not_this_grid(const TriangleArgs& a, uint32_t count) {
+  if (a.choice_mode == 0u || count == 0u) return false;
+  const bool ranges = plan_tri_choice_is_ranges(a.max_lod_tris, stream_slots(a, a.first_index_base, count), count, a.choice_waves);
+  return ranges != (a.choice_mode == 1u);
+}
+
 // Large frames launch the wave-per-command grid AND a workgroup-per-command grid; every workgroup of both asks this
 // (wave-uniform, three scalar loads) and one grid returns at once. The rule and its measurements: frame_plan.hpp.
 __device__ __forceinline__ bool tri_choice_is_block(const TriangleArgs& a) {
@@ -155,76 +259,147 @@ __device__ __forceinline__ bool tri_choice_is_block(const TriangleArgs& a) {
 #define MIP_TRI_MIN_WAVES_PER_SIMD 4
 #endif
 
-__global__ __launch_bounds__(256, MIP_TRI_MIN_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
+#ifndef MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD
+#define MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD 8
+#endif
+__device__ __forceinline__ uint32_t tri_size_class(uint32_t index_count) {
+  const uint32_t n_tris = index_count / 3u;
+  return n_tris ? 31u - (uint32_t)__builtin_clz(n_tris) : 0u;
+}
+
+__global__ __launch_bounds__(256, MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
-  if (a.index_total && tri_choice_is_block(a)) return;  // this frame is the workgroup-per-command grid's
+  if (a.index_total && tri_choice_is_block(a)) return;  // (round 4's pairing) this frame is the workgroup-per-command grid's
   const uint32_t count = *a.count;
+  if (tri_not_this_grid(a, count)) return;              // (round 5's pairing) this frame is the range kernel's
   float pv[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
 
-  // Commands differ 1000x in triangle count (LODs, mixed meshes): waves pull the next command
-  // from a ticket counter instead of striding over the list (measured: static striding left a
-  // third of the waves idle at 5 k commands). The counter is zeroed by the host per launch.
-  // Every lane takes part in the add (lane 0 adds 1, the others 0: the compiler folds the wave's
-  // adds into one atomic), so there is no divergent branch around it, and the loop is bounded
-  // by the command count whatever the counter holds.
+  // Commands differ 1000x in triangle count (LODs, mixed meshes): waves pull their work from a ticket counter instead of
+  // striding over the list (measured: static striding left a third of the waves idle at 5 k commands). The counter is
+  // zeroed by the host per launch. Every lane takes part in the add (lane 0 adds 1, the others 0: the compiler folds the
+  // wave's adds into one atomic), so there is no divergent branch around it, and the loop is bounded by the command count
+  // whatever the counter holds.
+  // Round 5 (a.order): a ticket is a run of commands of ONE size class in the list the sort kernels wrote, largest class
+  // first — the launch no longer ends with waves walking their last long command alone (19 % of the 100 k frame in round
+  // 4) — and a ticket of a small class is several commands (a same-address atomic takes ~11 ns: one per command was the
+  // whole launch at 258 k commands). Which wave walks which command changes nothing in the stream.
+  const bool sorted = a.order != nullptr;
+  const uint32_t n_tickets = sorted ? a.sort_info[kSortTickets + 31u] : count;
+#ifdef MIP_EXP_RANGE_TIMES  // experiment build (tools/r05_range_times.py): per wave {start, end, commands, triangles, first ticket end, -, -, -} behind the index buffer's capacity
+  uint32_t* exp_at = a.out_indices + a.capacity + 8u * (blockIdx.x * 4u + (threadIdx.x >> 6));
+  uint32_t exp_cmds = 0, exp_tris = 0;
+  if (lane == 0u) exp_at[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   for (uint32_t pulled = 0; pulled <= count; ++pulled) {
     const uint32_t old = atomicAdd(a.ticket, lane == 0u ? 1u : 0u);
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);  // wave-uniform: scalar loads below
-    if (c >= count) break;
-
-    const uint32_t index_count = a.cmds[c * kCmdWords + 0];
-    const uint32_t first_index = a.cmds[c * kCmdWords + 2];
-    const int32_t vertex_offset = (int32_t)a.cmds[c * kCmdWords + 3];
-    const uint32_t instance = a.cmds[c * kCmdWords + 4] - a.first_instance_base;
-    const uint32_t src_tri = a.src_index_offset[c] / 3u;  // index_buffer[indexOffset / 3 + id]
-    const uint32_t n_tris = index_count / 3u;
-    float model[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 col = a.model[(size_t)instance * 4 + q];
-      model[q * 4 + 0] = col.x; model[q * 4 + 1] = col.y; model[q * 4 + 2] = col.z; model[q * 4 + 3] = col.w;
+    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);  // wave-uniform: scalar loads below
+    if (ticket >= n_tickets) break;
+    uint32_t first = ticket, n_cmds = 1;
+    if (sorted) {
+      uint32_t d = 0, before = 0;
+      for (; d < 31u; ++d) {  // (n_tickets > ticket: the loop ends at the class that holds it)
+        const uint32_t upto = a.sort_info[kSortTickets + d];
+        if (ticket < upto) break;
+        before = upto;
+      }
+      const uint32_t batch = a.sort_info[kSortBatch + d];
+      const uint32_t class_end = d < 31u ? a.sort_info[kSortStart + d + 1u] : count;
+      first = a.sort_info[kSortStart + d] + (ticket - before) * batch;
+      n_cmds = class_end - first < batch ? class_end - first : batch;
     }
-    const bool affine = model_is_affine(model, a.geometry_finite);
-    const bool fits = (unsigned long long)first_index + index_count <= a.capacity;
-    if (!fits && lane == 0) raise_error(a.error_flag, kErrIndexOverflow);
-    const size_t dst_tri = (size_t)first_index / 3u;
-    const uint32_t* tri_indices = a.indices + (size_t)src_tri * 3;
-    uint32_t survivors = 0;
-
-    // one loop per path: the choice is per command, not per step
-    auto walk = [&](auto affine_tag) {
-      constexpr bool kAffine = decltype(affine_tag)::value;
-      // software pipeline: the index triple of step k+1 is in flight while step k gathers and tests
-      uint32_t n0 = 0, n1 = 0, n2 = 0;
-      if (lane < n_tris) {
-        const uint32_t* ip = tri_indices + (size_t)lane * 3;
-        n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
-      }
-      for (uint32_t t0 = 0; t0 < n_tris; t0 += 64u) {
-        const uint32_t t = t0 + lane;
-        const bool valid = t < n_tris;
-        const uint32_t i0 = n0, i1 = n1, i2 = n2;
-        if (t + 64u < n_tris) {
-          const uint32_t* ip = tri_indices + (size_t)(t + 64u) * 3;
-          n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
-        }
-        float v[9];
-        triangle_fetch(a.vertices, (long long)vertex_offset, i0, i1, i2, v);
-        const bool keep = valid && !triangle_test<kAffine>(model, pv, v);
-        const unsigned long long mask = __ballot(keep);
-        if (keep && fits) {
-          uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
-          dst[0] = i0; dst[1] = i1; dst[2] = i2;
-        }
-        survivors += (uint32_t)__popcll(mask);
-      }
-    };
-    if (affine) walk(std::true_type{});
-    else walk(std::false_type{});
-    if (lane == 0) a.cmds[c * kCmdWords + 0] = survivors * 3u;  // the command's final indexCount
+    // The SIMD issues its OLDEST wave first: left alone, the youngest wave of a SIMD walks its first command for most of the
+    // launch (first command done after 207 .. 943 us of a 990 us launch, 1 .. 8 commands per wave) and the launch ends with
+    // those waves alone on their SIMDs. A wave that has pulled fewer tickets asks for a higher issue priority: 196 .. 462 us,
+    // 3 .. 4 commands per wave (profiles/r05_wave_kernel_lifetimes.txt).
+    if (pulled == 0u) __builtin_amdgcn_s_setprio(3);
+    else if (pulled == 1u) __builtin_amdgcn_s_setprio(2);
+    else if (pulled == 2u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+    for (uint32_t k = 0; k < n_cmds; ++k) {
+      const uint32_t c = sorted ? a.order[first + k] : first + k;
+      const ChunkCmd m = chunk_load_cmd(a, 0u, c);
+      float model[16];
+      chunk_load_model(a, m.instance, model);
+      const bool affine = model_is_affine(model, a.geometry_finite);
+      const bool fits = (unsigned long long)m.first_index + m.index_count <= a.capacity;
+      if (!fits && lane == 0) raise_error(a.error_flag, kErrIndexOverflow);
+      // one loop per path: the choice is per command, not per step
+      const uint32_t survivors = m.n_tris == 0u ? 0u
+                                 : affine ? chunk_walk<true, true>(a, m, model, pv, 0u, m.n_tris, fits, (size_t)m.first_index / 3u, nullptr, lane)
+                                          : chunk_walk<false, true>(a, m, model, pv, 0u, m.n_tris, fits, (size_t)m.first_index / 3u, nullptr, lane);
+      // the command's final indexCount: beside the command when the re-compaction is told to look there (it must, when another
+      // grid may have taken the frame instead), else into it
+      if (lane == 0) (a.final_index_count ? a.final_index_count[c] : a.cmds[c * kCmdWords + 0]) = survivors * 3u;
+#ifdef MIP_EXP_RANGE_TIMES
+      if (lane == 0u && exp_cmds == 0u) exp_at[4] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+      exp_cmds += 1u; exp_tris += m.n_tris;
+#endif
+    }
   }
+#ifdef MIP_EXP_RANGE_TIMES
+  if (lane == 0u) { exp_at[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); exp_at[2] = exp_cmds; exp_at[3] = exp_tris; }
+#endif
+}
+
+// ---- commands by descending size class (round 5) ----
+// count: a histogram of the classes (LDS per workgroup, one global add per class and workgroup); the LAST workgroup to
+// add turns it into positions, tickets and batch sizes, largest class first. scatter: every command to its class's run
+// (the order inside a run is whatever the adds make it: it decides which wave walks which command, nothing else).
+__global__ __launch_bounds__(256) void mip_triangle_sort_count_kernel(const TriangleArgs a) {
+  __shared__ uint32_t s_hist[32];
+  __shared__ uint32_t s_last;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t count = *a.count;
+  if (tri_not_this_grid(a, count)) return;
+  if (tid < 32u) s_hist[tid] = 0u;
+  __syncthreads();
+  const uint32_t c = blockIdx.x * 256u + tid;
+  if (c < count) atomicAdd(&s_hist[tri_size_class(a.cmds[c * kCmdWords + 0])], 1u);
+  __syncthreads();
+  if (tid < 32u && s_hist[tid]) (void)__hip_atomic_fetch_add(&a.sort_info[kSortHist + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid == 0u) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // this workgroup's adds are visible before its arrival is
+    s_last = __hip_atomic_fetch_add(&a.sort_info[kSortDone], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last == 0u || tid != 0u) return;
+  uint32_t at = 0, tickets = 0;
+  for (uint32_t d = 0; d < 32u; ++d) {
+    const uint32_t k = 31u - d;
+    const uint32_t h = __hip_atomic_load(&a.sort_info[kSortHist + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a ticket is worth ~4 096 triangles, and at most 16 commands (a small command costs its start-up latency, not its triangles)
+    uint32_t batch = k >= 12u ? 1u : 4096u >> k;
+    if (batch > 16u) batch = 16u;
+    a.sort_info[kSortStart + d] = at;
+    a.sort_info[kSortCursor + k] = at;
+    a.sort_info[kSortBatch + d] = batch;
+    tickets += (h + batch - 1u) / batch;
+    a.sort_info[kSortTickets + d] = tickets;
+    at += h;
+  }
+}
+
+__global__ __launch_bounds__(256) void mip_triangle_sort_scatter_kernel(const TriangleArgs a, uint32_t* order) {
+  __shared__ uint32_t s_hist[32];
+  __shared__ uint32_t s_base[32];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t count = *a.count;
+  if (tri_not_this_grid(a, count)) return;
+  if (tid < 32u) s_hist[tid] = 0u;
+  __syncthreads();
+  const uint32_t c = blockIdx.x * 256u + tid;
+  uint32_t k = 0, rank = 0;
+  if (c < count) {
+    k = tri_size_class(a.cmds[c * kCmdWords + 0]);
+    rank = atomicAdd(&s_hist[k], 1u);
+  }
+  __syncthreads();
+  if (tid < 32u && s_hist[tid]) s_base[tid] = __hip_atomic_fetch_add(&a.sort_info[kSortCursor + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (c < count) order[s_base[k] + rank] = c;
 }
 
 // compact_draw_stream.comp runs after generate_work: commands whose triangles all died are
@@ -624,6 +799,286 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
     // the command's final indexCount — beside the command, never into it: a part of this command that has not started yet (its
     // successors have helped themselves past it) still needs the ORIGINAL indexCount to find its triangles
     if (part == kTriParts - 1u && tid == 0) a.final_index_count[c] = (prefix + total) * 3u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Round 5 — every frame size: the stage as EQUAL RANGES of the frame's triangle stream
+// ---------------------------------------------------------------------------------------
+// The reference cuts every instance's triangles into workgroups of 384 (generate_work.comp:56,74-75;
+// cull_pipeline.rs:560-576 dispatches ceil(tris / wg) of them): every unit of work is the same size. Rounds 1-4 handed a
+// WHOLE command (up to tens of thousands of triangles) to one wave or one workgroup from a ticket counter, and a launch
+// ended with waves walking their last command alone (up to 19 % of it: profiles/r04_triangle_bound_experiments.txt).
+// Here the frame's triangle stream is cut into equal RANGES, one per wave of a grid that is resident as a whole (a few
+// per wave when MIP_TUNE_TRI_RANGES_PER_WAVE says so); no ticket (11 ns per same-address atomic), no tail. Command c owns
+// the SLOTS
+//     [slot0(c), slot0(c) + indexCount(c) / 3),   slot0(c) = (firstIndex(c) - first_index_base) / 3
+// of that stream (firstIndex is already the running sum of indexCount over the emitted commands — the instance kernel's
+// prefix — so the slots of different commands are disjoint and ascending; index counts that are no multiple of 3 leave
+// unused slots). Range b = slots [b * S, (b + 1) * S), S = the stream's length over the number of ranges, in whole steps
+// of 64. The part of a command inside a range is a SEGMENT, walked 64 triangles per step with the command's matrix in
+// scalar registers, exactly as the wave-per-command kernel walks a whole command.
+//   * where a range starts: `range_first_cmd`, written by mip_triangle_range_map_kernel (one thread per command);
+//   * order: a command's survivors follow those of its earlier triangles. A segment whose command STARTS in the range
+//     knows its position (0) and writes as it goes. The one segment of a range that CONTINUES a command from earlier
+//     ranges — the first — needs that command's survivors there: it is TESTED at once, its 64-bit keep masks kept in LDS
+//     (8 bytes per step), every range publishes the survivors of its LAST segment as one tagged granule when it is
+//     through, and the continuing segment is WRITTEN one range later — after the wave's next range has been tested: by
+//     then the ranges it looks back at (claimed before it, by waves that are running) have published, and the look-back
+//     is one round trip instead of a wait for the slowest neighbour. The kept triangles' index triples are read again
+//     from the mesh's own index range (shared by every instance of the mesh: the L2 has it), eight steps in flight.
+//     A granule that is not there after the patient polls is not waited for: the wave counts that range's share itself
+//     (same triangles, same test) and publishes it — no wait depends on another wave ever running.
+// Slots per range, in whole steps of 64. A stream that gives every wave of the (resident) grid at most `ticket_slots`
+// slots is cut into one range per wave, dealt statically: nothing to balance, no ticket. A longer stream is cut into
+// ranges of `ticket_slots`: a wave's first range is its own, the others are pulled from a counter — waves do NOT advance
+// at the same rate (the SIMD issues its oldest wave first: equal static shares ended 1.1 .. 3.1 ms apart on the 300 k
+// frame, profiles/r05_range_wave_lifetimes.txt), and a ticket per 4 096 triangles is one per ~20 ns of the launch, above
+// the ~11 ns a same-address atomic takes.
+constexpr uint32_t kRangeMinSlots = 256;
+constexpr uint32_t kRangeMaxSlots = 8192;   // = kRangeMaskSteps * 64: a continuing segment's masks always fit
+__host__ __device__ __forceinline__ uint32_t range_slots(uint32_t total, uint32_t n_waves, uint32_t ticket_slots) {
+  const uint32_t one = (uint32_t)((((unsigned long long)total + n_waves - 1u) / n_waves + 63u) / 64u) * 64u;
+  if (one <= ticket_slots) return one < kRangeMinSlots ? kRangeMinSlots : one;
+  return ticket_slots;
+}
+
+// range b starts with the first command whose slots END behind b * S
+__global__ __launch_bounds__(256) void mip_triangle_range_map_kernel(const TriangleChunkArgs ca) {
+  const TriangleArgs& a = ca.t;
+  const uint32_t count = *a.count;
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= count || tri_not_this_grid(a, count)) return;
+  const uint32_t base = ca.first_index_base;
+  const uint32_t S = range_slots(stream_slots(a, base, count), ca.n_waves, ca.ticket_slots);
+  const uint32_t index_count = a.cmds[c * kCmdWords + 0], first_index = a.cmds[c * kCmdWords + 2];
+  const uint32_t n_tris = index_count / 3u;
+  const uint32_t end = (first_index - base) / 3u + n_tris;
+  const uint32_t prev_end = c ? (a.cmds[(c - 1u) * kCmdWords + 2] - base) / 3u + a.cmds[(c - 1u) * kCmdWords + 0] / 3u : 0u;
+  if ((unsigned long long)first_index + index_count > a.capacity) raise_error(a.error_flag, kErrIndexOverflow);
+  if (n_tris == 0u) a.final_index_count[c] = 0u;  // (an indexCount of 1 or 2: no range ever visits it)
+  uint32_t b = (prev_end + S - 1u) / S;
+  uint32_t b_end = (end + S - 1u) / S;
+  if (b_end > ca.ranges_cap) b_end = ca.ranges_cap;  // (only commands that do not fit the index buffer reach past it: reported above)
+  for (; b < b_end; ++b) ca.range_first_cmd[b] = c;
+}
+
+#ifndef MIP_TRI_CHUNK_WAVES_PER_SIMD
+#define MIP_TRI_CHUNK_WAVES_PER_SIMD 8
+#endif
+constexpr uint32_t kChunkPolls = 128;        // x (s_sleep 2 + one load): some tens of microseconds
+constexpr uint32_t kRangeMaskSteps = kRangeMaxSlots / 64u;  // keep masks of a continuing segment: 1 KB of LDS per wave and buffer
+
+// The same walk without the software pipeline and with the path chosen at run time: the rare paths (a range's share
+// counted for a wave that has not published; the tail of a continuing segment beyond the mask buffer).
+template <bool kWrite>
+__device__ __forceinline__ uint32_t chunk_rewalk(const TriangleArgs& a, uint32_t base, const float (&pv)[16], uint32_t c, uint32_t b, uint32_t e, size_t dst_tri) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const ChunkCmd m = chunk_load_cmd(a, base, c);
+  float model[16];
+  chunk_load_model(a, m.instance, model);
+  const bool affine = model_is_affine(model, a.geometry_finite);
+  const uint32_t* tri_indices = a.indices + (size_t)m.src_tri * 3;
+  uint32_t survivors = 0;
+  for (uint32_t t0 = b; t0 < e; t0 += 64u) {
+    const uint32_t t = t0 + lane;
+    const bool valid = t < e;
+    uint32_t j0 = 0, j1 = 0, j2 = 0;
+    if (valid) {
+      const uint32_t* ip = tri_indices + (size_t)t * 3;
+      j0 = ip[0]; j1 = ip[1]; j2 = ip[2];
+    }
+    const bool keep = valid && !triangle_culled(affine, model, pv, a.vertices, (long long)m.vertex_offset, j0, j1, j2);
+    const unsigned long long mask = __ballot(keep);
+    if constexpr (kWrite) {
+      if (keep) {
+        uint32_t* dst = a.out_indices + (dst_tri + survivors + lanes_below(mask)) * 3;
+        dst[0] = j0; dst[1] = j1; dst[2] = j2;
+      }
+    }
+    survivors += (uint32_t)__popcll(mask);
+  }
+  return survivors;
+}
+
+// A range's continuing segment between its test and its write.
+struct ChunkPending {
+  bool valid, ends, fits;
+  uint32_t b, c, survivors, slot0, first_index, src_tri, t_begin, t_end;
+};
+
+// The write of a tested continuing segment: the kept triangles' index triples are read again through a descriptor over
+// the segment's part of the mesh's index range (a lane without a survivor gets an offset beyond it: no load, no branch)
+// and stored through one over the segment's place in the stream — twelve steps' loads in flight, no address arithmetic
+// in vector registers (the step advances the scalar offset).
+__device__ __forceinline__ void chunk_write_deferred(const TriangleArgs& a, uint32_t base, const float (&pv)[16], const ChunkPending& p,
+                                                     const unsigned long long* masks, uint32_t prefix, uint32_t lane) {
+  if (!p.fits) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's masks are every lane's from here on (the wave's own LDS: no barrier)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t n_steps = (p.t_end - p.t_begin + 63u) / 64u;
+  const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.indices) + ((size_t)p.src_tri + p.t_begin) * 3, 0,
+                                                                       (int)((p.t_end - p.t_begin) * 12u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.out_indices + ((size_t)p.first_index / 3u + prefix) * 3, 0,
+                                                                       (int)(p.survivors * 12u), 0x00020000);
+  const uint32_t lane_offset = lane * 12u;
+  uint32_t at = 0;  // survivors written so far
+  constexpr uint32_t kBatch = 12;
+  for (uint32_t s0 = 0; s0 < n_steps; s0 += kBatch) {
+    unsigned long long mk[kBatch];
+    tri_u32x3 idx[kBatch];
+#pragma unroll
+    for (uint32_t q = 0; q < kBatch; ++q) {
+      const unsigned long long raw = s0 + q < n_steps ? masks[s0 + q] : 0ull;  // the same for every lane: kept in scalar registers
+      mk[q] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(raw >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)raw);
+      const bool keep = ((mk[q] >> lane) & 1ull) != 0ull;
+      idx[q] = __builtin_amdgcn_raw_buffer_load_b96(src, (int)(keep ? lane_offset : kTriDropOffset), (int)((s0 + q) * 768u), 0);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kBatch; ++q) {
+      const bool keep = ((mk[q] >> lane) & 1ull) != 0ull;
+      __builtin_amdgcn_raw_buffer_store_b96(idx[q], out, (int)(keep ? (at + lanes_below(mk[q])) * 12u : kTriDropOffset), 0, MIP_TRI_STORE_AUX);
+      at += (uint32_t)__popcll(mk[q]);
+    }
+  }
+}
+
+// Σ survivors of command p.c in the ranges [b0, p.b) — every one of them ends with a segment of that command.
+__device__ __forceinline__ uint32_t chunk_lookback(const TriangleChunkArgs& ca, uint32_t S, const float (&pv)[16], const ChunkPending& p, uint32_t lane) {
+  const TriangleArgs& a = ca.t;
+  const uint32_t b0 = p.slot0 / S;
+  uint32_t prefix = 0;
+  for (uint32_t hi = p.b; hi > b0;) {
+    const uint32_t lo = hi - b0 > 64u ? hi - 64u : b0;
+    const uint32_t j = lo + lane;
+    const bool need = j < hi;
+    bool ready = !need;
+    uint32_t got = 0, polls = 0;
+    for (;;) {
+      if (!ready) {
+        const unsigned long long g = status_load(&ca.range_status[j]);
+        if ((uint32_t)(g >> 32) == ca.epoch) { ready = true; got = (uint32_t)g; }
+      }
+      if (__all(ready)) break;
+      if (__builtin_expect(++polls > kChunkPolls, 0)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    unsigned long long missing = __ballot(!ready);
+    while (__builtin_expect(missing != 0ull, 0)) {  // wave-uniform: count that range's share of the command ourselves
+      const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(missing));
+      const uint32_t jj = lo + q;
+      unsigned long long g = status_load(&ca.range_status[jj]);
+      if ((uint32_t)(g >> 32) != ca.epoch) {
+        const uint32_t b_slot = jj * S > p.slot0 ? jj * S : p.slot0;
+        const uint32_t b = b_slot - p.slot0, e = (jj + 1u) * S - p.slot0;  // (the command goes on past range jj: e < n_tris)
+        const uint32_t survivors = chunk_rewalk<false>(a, ca.first_index_base, pv, p.c, b, e, 0);
+        g = ((unsigned long long)ca.epoch << 32) | survivors;
+        if (lane == 0u) {
+          __hip_atomic_store(&ca.range_status[jj], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          (void)__hip_atomic_fetch_add(a.help_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (lane == q) got = (uint32_t)g;
+      missing &= ~(1ull << q);
+    }
+    prefix += wave_sum(got);
+    hi = lo;
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(256, MIP_TRI_CHUNK_WAVES_PER_SIMD) void mip_triangle_cull_ranges_kernel(const TriangleChunkArgs ca) {
+  const TriangleArgs& a = ca.t;
+  __shared__ unsigned long long s_masks[4][2][kRangeMaskSteps];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t count = *a.count;
+  if (count == 0u || tri_not_this_grid(a, count)) return;
+  const uint32_t base = ca.first_index_base;
+  const uint32_t total = stream_slots(a, base, count);
+  const uint32_t S = range_slots(total, ca.n_waves, ca.ticket_slots);
+  uint32_t n_ranges = (total + S - 1u) / S;
+  if (n_ranges > ca.ranges_cap) n_ranges = ca.ranges_cap;
+  float pv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
+
+  const uint32_t n_waves = gridDim.x * 4u;
+#ifdef MIP_EXP_RANGE_TIMES  // experiment build (tools/r05_range_times.py): when every wave started and ended, behind the index buffer's capacity
+  struct RangeTimes {
+    uint32_t* at; uint32_t lane;
+    __device__ RangeTimes(uint32_t* p, uint32_t l) : at(p), lane(l) { if (lane == 0u) at[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> 0); }
+    __device__ ~RangeTimes() { if (lane == 0u) at[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> 0); }
+  } range_times(a.out_indices + a.capacity + 2u * (blockIdx.x * 4u + wave), lane);
+#endif
+  // the previous range's continuing segment: tested and published, written after this range's test
+  ChunkPending pend{};
+  uint32_t buf = 0;
+  // a wave's first range is its own; the others come from the counter (zeroed by the host), which starts behind the static ones
+  for (uint32_t dealt = blockIdx.x * 4u + wave;;
+       dealt = n_ranges <= n_waves ? n_ranges : n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(a.ticket, lane == 0u ? 1u : 0u))) {
+    ChunkPending cur{};
+    const bool walk = dealt < n_ranges;
+    if (walk) {
+      uint32_t b = dealt;
+#ifdef MIP_DEBUG_STAMPS
+      if (ca.debug_reverse) b = n_ranges - 1u - dealt;
+      const bool skip_publish = ca.debug_skip_part && (b & 15u) == ca.debug_skip_part - 1u;  // fault injection
+#else
+      const bool skip_publish = false;
+#endif
+      const uint32_t slot_lo = b * S, slot_hi = slot_lo + S;
+      uint32_t last_survivors = 0;
+      uint32_t c = ca.range_first_cmd[b];
+      ChunkCmd m{};
+      if (c < count) m = chunk_load_cmd(a, base, c);
+      while (c < count) {
+        if (m.slot0 >= slot_hi) break;
+        const uint32_t seg_lo = m.slot0 > slot_lo ? m.slot0 : slot_lo;
+        const uint32_t seg_hi = m.slot0 + m.n_tris < slot_hi ? m.slot0 + m.n_tris : slot_hi;
+        const bool ends_here = m.slot0 + m.n_tris <= slot_hi;
+        ChunkCmd m_after{};
+        if (ends_here && c + 1u < count) m_after = chunk_load_cmd(a, base, c + 1u);  // in flight while this segment is walked
+        if (seg_lo < seg_hi) {
+          const uint32_t t_begin = seg_lo - m.slot0, t_end = seg_hi - m.slot0;
+          float model[16];
+          chunk_load_model(a, m.instance, model);
+          const bool affine = model_is_affine(model, a.geometry_finite);
+          const bool fits = (unsigned long long)m.first_index + m.index_count <= a.capacity;  // (reported by the map kernel)
+          const size_t dst_tri = (size_t)m.first_index / 3u;
+          uint32_t survivors;
+          if (t_begin > 0u) {  // continues a command that started in an earlier range (only a range's first segment can)
+            survivors = affine ? chunk_walk<true, false>(a, m, model, pv, t_begin, t_end, fits, dst_tri, s_masks[wave][buf], lane)
+                               : chunk_walk<false, false>(a, m, model, pv, t_begin, t_end, fits, dst_tri, s_masks[wave][buf], lane);
+            cur.valid = true; cur.ends = ends_here; cur.fits = fits; cur.b = b; cur.c = c; cur.survivors = survivors;
+            cur.slot0 = m.slot0; cur.first_index = m.first_index; cur.src_tri = m.src_tri; cur.t_begin = t_begin; cur.t_end = t_end;
+          } else {             // the command starts here: its survivors' position is known
+            survivors = affine ? chunk_walk<true, true>(a, m, model, pv, t_begin, t_end, fits, dst_tri, nullptr, lane)
+                               : chunk_walk<false, true>(a, m, model, pv, t_begin, t_end, fits, dst_tri, nullptr, lane);
+            if (ends_here && lane == 0u) a.final_index_count[c] = survivors * 3u;
+          }
+          last_survivors = survivors;
+        }
+        if (!ends_here) break;
+        m = m_after;
+        ++c;
+      }
+      // ---- publish the last segment's survivors (the next range needs them iff that segment's command goes on there) ----
+      if (lane == 0u && !skip_publish)
+        __hip_atomic_store(&ca.range_status[b], ((unsigned long long)ca.epoch << 32) | last_survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the PREVIOUS range's continuing segment: behind the survivors of its command in the earlier ranges ----
+    if (pend.valid) {
+      const uint32_t prefix = chunk_lookback(ca, S, pv, pend, lane);
+      chunk_write_deferred(a, base, pv, pend, s_masks[wave][buf ^ 1u], prefix, lane);
+      if (pend.ends && lane == 0u) a.final_index_count[pend.c] = (prefix + pend.survivors) * 3u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // those masks have been read before a later range writes its own there
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!walk) break;
+    pend = cur;
+    buf ^= 1u;
   }
 }
 

@@ -74,9 +74,18 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
   if (rq.triangles) {
     CHECK(p.tri_blocks >= 1, "a triangle launch has a grid");
     CHECK(p.need_part_status == (p.tri == TriangleKernel::parts), "granules only for the parts kernel");
-    CHECK(p.tri_reset_ticket == (p.tri == TriangleKernel::waves || p.tri_block_tickets), "the counter is zeroed exactly for the kernels that pull from it");
+    CHECK(p.need_chunk_scratch == (p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted), "range map and granules only for the range kernel");
+    CHECK((p.tri_wave_blocks != 0) == (p.tri == TriangleKernel::sorted), "the second grid only where the device chooses");
+    CHECK(p.tri_reset_ticket == (p.tri == TriangleKernel::waves || p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted || p.tri_block_tickets), "the counter is zeroed exactly for the kernels that pull from it");
     CHECK(p.tri_block_tickets == (p.tri == TriangleKernel::block && st.n > 32768u), "the workgroup kernel pulls tickets when commands far outnumber workgroups");
-    if (p.tri == TriangleKernel::parts) {
+    if (p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted) {
+      CHECK(st.n >= st.tri_chunks_from && !st.tri_block_threads, "range kernel preconditions");
+      CHECK((p.tri == TriangleKernel::sorted) == (st.n > st.tri_block_max), "sorted commands + device-side choice above tri_block_max");
+      if (p.tri == TriangleKernel::sorted) CHECK(p.tri_wave_blocks == st.cu_count * 8u, "wave grid");
+      CHECK(p.tri_blocks == st.cu_count * st.tri_chunk_blocks_per_cu && p.tri_threads == 256, "chunk grid: resident as a whole");
+      CHECK((uint64_t)p.tri_map_blocks * 256u >= st.n && (uint64_t)(p.tri_map_blocks - 1u) * 256u < st.n, "chunk map: one thread per possible command");
+    } else if (p.tri == TriangleKernel::parts) {
+      CHECK(st.n < st.tri_chunks_from || st.tri_block_threads, "the chunk kernel comes first where it is switched on");
       CHECK(st.frame_slots == 1 && st.n <= st.tri_parts_max && !st.tri_block_threads && st.max_lod_tris <= 16u * 256u * 8u, "parts kernel preconditions");
       CHECK(p.tri_blocks <= st.cu_count * 4u && p.tri_blocks <= st.n * 16u, "parts grid: resident as a whole, no more blocks than items");
     } else if (p.tri == TriangleKernel::block) {
@@ -92,7 +101,7 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
     CHECK((p.recompact == Recompact::single) == (st.n <= st.tri_block_max), "one-workgroup re-compaction for small frames");
     if (p.recompact == Recompact::wide) CHECK((uint64_t)p.recompact_blocks * 1024u >= st.n, "wide re-compaction covers the list");
   } else {
-    CHECK(!p.need_part_status && !p.tri_reset_ticket, "no triangle scratch without the stage");
+    CHECK(!p.need_part_status && !p.need_chunk_scratch && !p.tri_reset_ticket && !p.tri_map_blocks, "no triangle scratch without the stage");
   }
 }
 
@@ -109,6 +118,14 @@ static void check_tri_choice() {
       {"an empty frame", 15452, 0u, 0u, true},                {"one command", 15452, 15452u * 3u, 1u, true}};
   for (const Row& r : rows)
     CHECK(plan_tri_choice_is_block(r.max_lod_tris, r.index_total, r.commands) == r.block, "triangle grid choice for %s", r.what);
+  // round 5: range kernel or size-sorted wave-per-command kernel, on the frames it was measured on (8 192 waves)
+  struct Row5 { const char* what; uint32_t max_lod_tris, total_tris, commands; bool ranges; };
+  const Row5 rows5[] = {
+      {"mixed 70 k", 23358, 41000000u, 18220, true},      {"mixed 100 k", 23358, 57600000u, 25776, true},   {"mixed 200 k", 23358, 114400000u, 51355, true},
+      {"mixed 400 k", 23358, 229300000u, 103015, true},   {"mixed 1 M", 23358, 571400000u, 257864, false},  {"one mesh 70 k", 15452, 149500000u, 18353, false},
+      {"one mesh 100 k", 15452, 213000000u, 26154, false}, {"one mesh 300 k", 15452, 638000000u, 78400, false}};
+  for (const Row5& r : rows5)
+    CHECK(plan_tri_choice_is_ranges(r.max_lod_tris, r.total_tris, r.commands, 8192u) == r.ranges, "range / sorted-wave choice for %s", r.what);
   // monotone: more triangles in the frame never turn the wave-per-command choice back into the workgroup one
   for (uint32_t max_tris : {12u, 1000u, 23358u})
     for (uint32_t commands : {1u, 1000u, 100000u}) {
@@ -134,8 +151,10 @@ int main() {
           for (int force_order : {0, 1})
             for (uint32_t tri_threads : {0u, 512u})
               for (uint32_t n_joints : {0u, 19u})
-                for (uint32_t lod_tris : {32768u, 32769u}) {
+                for (uint32_t lod_tris : {32768u, 32769u})
+                 for (uint32_t chunks_from : {0u, 2000u, 0xffffffffu}) {
                   PlanState st;
+                  st.tri_chunks_from = chunks_from;
                   st.n = n;
                   st.n_meshes = n_meshes;
                   st.max_instances = n ? n : 1u;

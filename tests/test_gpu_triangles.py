@@ -67,12 +67,28 @@ def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     assert 0 < survivors < int(r["draw_cmds"]["indexCount"].astype(np.int64).sum())  # something was culled, something survived
 
 
-@pytest.mark.parametrize("mode", ["wave", "wave_only", "tickets", "tickets_x4", "block256", "block512", "block1024", "parts"])
+@pytest.mark.parametrize("mode", ["ranges", "ranges_ticketed", "ranges_or_sorted_waves", "sorted_waves", "ranges_of_a_large_frame",
+                                  "wave", "wave_only", "tickets", "tickets_x4", "block256", "block512", "block1024", "parts"])
 def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
-    """The library picks sixteen parts per command, a 256/512/1024-thread workgroup per command (dealt by a stride, or
-    pulling tickets — one or four commands each) or one wave per command by instance count and, for large frames, on the
-    device from the frame's totals; here each variant is forced (tuning variables, read by mip_create and at launch) onto
-    the same mixed scene."""
+    """Round 5: the stage is the range kernel (equal ranges of the triangle stream, one per wave, or — long streams — ranges
+    of MIP_TUNE_TRI_RANGE_SLOTS pulled from a counter) and, above 65 536 instances, the range kernel or the wave-per-command
+    kernel over commands sorted by size class, chosen on the device. The round-4 kernels stay selectable
+    (MIP_TUNE_TRI_CHUNKS_FROM=4294967295): sixteen parts per command, a 256/512/1024-thread workgroup per command (dealt by
+    a stride, or pulling tickets — one or four commands each), one wave per command in list order. Each variant is forced
+    (tuning variables, read by mip_create and at launch) onto the same mixed scene."""
+    if mode == "ranges":
+        pass                                                     # the default at this size: one range per wave
+    elif mode == "ranges_ticketed":
+        monkeypatch.setenv("MIP_TUNE_TRI_RANGE_SLOTS", "256")    # a long stream by this measure: 256-slot ranges, most of them pulled from the counter
+    elif mode in ("ranges_or_sorted_waves", "sorted_waves", "ranges_of_a_large_frame"):
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")        # the large-frame path: sort kernels + both grids, one chosen on the device ...
+        if mode == "sorted_waves":
+            monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "waves")   # ... forced to the wave-per-command grid
+        elif mode == "ranges_of_a_large_frame":
+            monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "block")   # ... forced to the range kernel's
+            monkeypatch.setenv("MIP_TUNE_TRI_RANGE_SLOTS", "512")
+    else:
+        monkeypatch.setenv("MIP_TUNE_TRI_CHUNKS_FROM", "4294967295")  # the round-4 kernels
     if mode in ("wave", "wave_only", "tickets", "tickets_x4"):
         monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")   # the large-frame path: both grids, one chosen on the device ...
         monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "0")
@@ -113,6 +129,7 @@ def test_wave_kernel_vertex_ring_on_every_mesh_layout(ra, oracle_mod, monkeypatc
     the consolidated buffer (the ring loads ahead of the indices it has seen: clamped at the buffer's end)."""
     monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
     monkeypatch.setenv("MIP_TUNE_TRI_PARTS_MAX", "0")
+    monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "waves")  # (round 5: the large-frame pairing is range kernel | sorted wave-per-command kernel)
     s = ra.scene.make_scene(config, n=n, all_visible=(config == 2))
     s["pos"][11, 1] = np.nan
     vertices, indices = ra.scene.make_geometry(s["meshes"], ordering=ordering)
@@ -145,6 +162,55 @@ def test_triangle_cull_special_instances_and_bases(ra, oracle_mod):
     got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity, first_instance_base=1000)
     assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes()
     assert np.array_equal(got_out, want_out)
+
+
+@pytest.mark.parametrize("range_slots", [None, "256"])
+def test_triangle_cull_index_base_and_index_counts_that_are_no_multiple_of_three(ra, oracle_mod, monkeypatch, range_slots):
+    """The range kernel numbers the frame's triangles by (firstIndex - first_index_base) / 3: a first_index_base that is no
+    multiple of 3, and meshes whose index counts are not (the last one or two indices of a command are no triangle; such
+    commands leave unused slots in the stream, and a command of one or two indices has no triangle at all), with one range
+    per wave and with 256-slot ranges: bytes equal to the oracle's."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    if range_slots:
+        monkeypatch.setenv("MIP_TUNE_TRI_RANGE_SLOTS", range_slots)
+    s = ra.scene.make_scene(3, n=5000)
+    meshes = s["meshes"].copy()
+    for k in range(len(meshes)):
+        for lod in range(int(meshes["n_lods"][k])):
+            if (k + lod) % 3 == 1 and meshes["index_len"][k][lod] > 4:
+                meshes["index_len"][k][lod] -= 1 + (k % 2)
+    meshes["index_len"][5][:] = 2   # commands without a triangle
+    meshes["index_len"][9][:] = 1
+    s["meshes"] = meshes
+    vertices, indices = ra.scene.make_geometry(ra.scene.make_scene(3, n=5000)["meshes"])  # the geometry of the unshortened table
+    pv = ra.scene.default_pv()
+    base = 5
+    r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], first_index_base=base, threads=8)
+    capacity = base + r["draw_index_total"] + 3
+    want_cmds, want_out, _ = oracle_mod.cull_all_triangles(r, s["pos"], s["mesh_id"], s["meshes"], s["cam_pos"], pv, vertices, indices, out_capacity=capacity)
+    dev = torch.device("cuda", 0)
+    n = s["n"]
+    with ra.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"])) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_geometry(vertices, indices)
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        model = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+        scal = torch.zeros(8, dtype=torch.int32, device=dev)
+        out = torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            out.fill_(-1)
+            torch.cuda.synchronize()
+            p.run_device(make_frame(s["planes"], s["cam_pos"], first_index_base=base, pv=pv), model=model.data_ptr(), draw_cmds=cmds.data_ptr(),
+                         draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, culled_index_buffer=out.data_ptr(), culled_index_capacity=capacity)
+        count = int(scal[0].item())
+        got_cmds = cmds[:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+        assert count == len(want_cmds) and got_cmds.tobytes() == want_cmds.tobytes()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want_out)
 
 
 def test_triangle_cull_with_non_finite_positions(ra, oracle_mod):
@@ -211,11 +277,13 @@ def test_triangle_cull_at_baseline_sizes(ra, oracle_mod, config, n):
 
 @pytest.mark.parametrize("fault", ["reverse", "skip"])
 def test_parts_kernel_does_not_depend_on_who_runs_when(oracle_mod, fault):
-    """The parts kernel (16 work items per command, a part writes its survivors behind those of the earlier parts of its
-    command) in the diagnostic build, with the work items dealt from the LAST one down ("reverse": later parts start first),
-    and with one part of every command that NEVER publishes ("skip": its successors have to count its survivors
-    themselves — MipTimings.prefix_helps says they did): the stream still equals the oracle's. No wait depends on another
-    workgroup ever running (rounds 2-3: a bounded wait, MIP_ERR_TIMEOUT and the kernel switched off for the context)."""
+    """The kernels that cut a command between waves — round 5's range kernel (a range's continuing segment goes behind the
+    survivors its command has in the earlier ranges), with one range per wave and with 256-slot ranges pulled from the
+    counter, and round 4's parts kernel (16 work items per command) — in the diagnostic build, with the work dealt from the
+    LAST item down ("reverse": later ranges start first), and with every 16th range / one part of every command that NEVER
+    publishes ("skip": its successors have to count its survivors themselves — MipTimings.prefix_helps says they did): the
+    stream still equals the oracle's. No wait depends on another workgroup ever running (rounds 2-3: a bounded wait,
+    MIP_ERR_TIMEOUT and the kernel switched off for the context)."""
     import os
     import subprocess
     import sys
@@ -234,7 +302,11 @@ import numpy as np
 import oracle, renderer_amd
 from test_gpu_triangles import _oracle, _run_gpu
 import torch
-for config, n in ((3, 3000), (2, 700)):
+for config, n, knobs in ((3, 3000, {}), (2, 700, {}), (3, 3000, {"MIP_TUNE_TRI_RANGE_SLOTS": "256"}), (2, 700, {"MIP_TUNE_TRI_RANGE_SLOTS": "256"}),
+                         (3, 3000, {"MIP_TUNE_TRI_CHUNKS_FROM": "4294967295"}), (2, 700, {"MIP_TUNE_TRI_CHUNKS_FROM": "4294967295"})):
+    for k in ("MIP_TUNE_TRI_RANGE_SLOTS", "MIP_TUNE_TRI_CHUNKS_FROM"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)   # (read when the context is created)
     s = renderer_amd.scene.make_scene(config, n=n)
     vertices, indices = renderer_amd.scene.make_geometry(s["meshes"])
     pv = renderer_amd.scene.default_pv()
@@ -242,9 +314,9 @@ for config, n in ((3, 3000), (2, 700)):
     capacity = r0["draw_index_total"] + 3
     r, want_cmds, want_out = _oracle(oracle, s, vertices, indices, pv, capacity)
     got_cmds, count, total, got_out = _run_gpu(renderer_amd, s, vertices, indices, pv, capacity, frames=2)
-    assert count == len(want_cmds), (config, n, count, len(want_cmds))
-    assert got_cmds.tobytes() == want_cmds.tobytes(), (config, n, "commands", int((got_cmds != want_cmds).sum()))
-    assert np.array_equal(got_out, want_out), (config, n, "index stream", int((got_out != want_out).sum()), int(np.nonzero(got_out != want_out)[0][0]))
+    assert count == len(want_cmds), (config, n, knobs, count, len(want_cmds))
+    assert got_cmds.tobytes() == want_cmds.tobytes(), (config, n, knobs, "commands", int((got_cmds != want_cmds).sum()))
+    assert np.array_equal(got_out, want_out), (config, n, knobs, "index stream", int((got_out != want_out).sum()), int(np.nonzero(got_out != want_out)[0][0]))
     if sys.argv[2] == "skip":   # (in reverse order the predecessors are usually published in time by their own workgroups)
         assert _run_gpu.last_timings["prefix_helps"] > 0, _run_gpu.last_timings
 print("PARTS OK")
