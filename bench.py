@@ -985,10 +985,16 @@ def run_sharded(args, torch, dist, renderer_amd, scene, make_frame, device, loca
             except Exception as e:  # noqa: BLE001
                 extra["single_gpu_same_workload"] = {"error": f"{type(e).__name__}: {e}"}
         dist.barrier()
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    # the CPU restatement beside the GPU number on EVERY line (round 4 carried it at N = 1 only): rank 0 times a bounded sample of its
+    # own shard's scene outside the timed region while the other ranks wait at the barrier
+    if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(s, args.cpu_seconds)
+        if world > 1:
+            result["cpu_baseline"]["sample"] = f"rank 0's shard of the {n_total}-instance scene; " + str(result["cpu_baseline"].get("sample", ""))
     elif rank == 0:
-        result["cpu_baseline"] = None  # timed on rank 0 at N = 1 only (the N = 1 line carries it)
+        result["cpu_baseline"] = None  # --no-cpu-baseline
+    if world > 1:
+        dist.barrier()
     pipe.close()
 
 

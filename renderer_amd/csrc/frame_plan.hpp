@@ -13,7 +13,10 @@
 
 namespace mip {
 
-constexpr uint32_t kPlanTile = 256;               // = kTile (instance_kernel.hpp; static_assert in api_frame.hip)
+#ifndef MIP_TILE
+#define MIP_TILE 256
+#endif
+constexpr uint32_t kPlanTile = MIP_TILE;          // = kTile (instance_kernel.hpp; static_assert in api_frame.hip)
 constexpr uint32_t kPlanTriParts = 16;            // = kTriParts
 constexpr uint32_t kPlanTriPartMaxT = 8;          // = kTriPartMaxT
 

@@ -45,6 +45,12 @@ namespace mip {
 
 constexpr uint32_t kTile = MIP_TILE;      // instances per tile == threads per workgroup
 constexpr uint32_t kWaves = kTile / 64;   // wave64
+constexpr uint32_t kPieces = kTile / 16;  // 1-KiB pieces of a tile's matrices: one store instruction of a wave each
+static_assert(kWaves >= 2, "wave 0 resolves the prefix while the other waves store");
+// Waves 1 .. kWaves-1 store ALL pieces of the tile (wave 0's too), in contiguous runs: the first piece of wave w's run
+// (256 instances: 0, 6, 11, 16 — runs of 6 + 5 + 5 KiB).
+__host__ __device__ constexpr uint32_t store_run_first(uint32_t w) { return ((w - 1u) * kPieces + kWaves - 2u) / (kWaves - 1u); }
+static_assert(store_run_first(1) == 0 && store_run_first(kWaves) == kPieces, "the runs cover the tile");
 constexpr uint32_t kCmdWords = 5;         // VkDrawIndexedIndirectCommand = 5 dwords
 constexpr uint32_t kCmdLdsWords = 6;      // in LDS each command also carries its source index offset
 
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     }
     MIP_STAMP(2);
     if (wave != 0) {  // waves 1-3 store all sixteen pieces (wave 0's too): wave 0 has nothing left to store after its copy-out
-      const uint32_t p0 = wave == 1u ? 0u : (wave == 2u ? 6u : 11u), p1 = wave == 1u ? 6u : (wave == 2u ? 11u : 16u);
+      const uint32_t p0 = store_run_first(wave), p1 = store_run_first(wave + 1u);  // 6 + 5 + 5 pieces
       for (uint32_t p = p0; p < p1; ++p) store_piece(p);
       if (wave == 1) store_bitmap();
       store_aabb();
@@ -1166,7 +1172,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // of the tile's prefix and then copies the commands out.
   if (wave != 0) {
     // contiguous runs of 6 + 5 + 5 KiB
-    const uint32_t p0 = wave == 1u ? 0u : (wave == 2u ? 6u : 11u), p1 = wave == 1u ? 6u : (wave == 2u ? 11u : 16u);
+    const uint32_t p0 = store_run_first(wave), p1 = store_run_first(wave + 1u);
     for (uint32_t p = p0; p < p1; ++p) store_piece(p);
     if (wave == 1) store_bitmap();
     store_aabb();

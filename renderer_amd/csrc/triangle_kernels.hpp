@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
 // slots is cut into one range per wave, dealt statically: nothing to balance, no ticket. A longer stream is cut into
 // ranges of `ticket_slots`: a wave's first range is its own, the others are pulled from a counter — waves do NOT advance
 // at the same rate (the SIMD issues its oldest wave first: equal static shares ended 1.1 .. 3.1 ms apart on the 300 k
-// frame, profiles/r05_range_wave_lifetimes.txt), and a ticket per 4 096 triangles is one per ~20 ns of the launch, above
+// frame, profiles/r05_wave_kernel_lifetimes.txt), and a ticket per 4 096 triangles is one per ~20 ns of the launch, above
 // the ~11 ns a same-address atomic takes.
 constexpr uint32_t kRangeMinSlots = 256;
 constexpr uint32_t kRangeMaxSlots = 8192;   // = kRangeMaskSteps * 64: a continuing segment's masks always fit

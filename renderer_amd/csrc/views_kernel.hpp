@@ -98,7 +98,9 @@ __global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArg
   constexpr uint32_t kStaged = 4;
   __shared__ __attribute__((aligned(16))) uint32_t s_cmd[kMaxViews][kTile * kStaged];
   __shared__ uint32_t s_wave_count[kMaxViews][kWaves], s_wave_sum[kMaxViews][kWaves];
+#if MIP_TILE >= 256  // (tile-size experiment builds, tools/r05_cfg2_tile128.sh, do not run this kernel)
   static_assert(kWaves >= kMaxViews, "one wave per view finishes that view");
+#endif
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   uint32_t tile = blockIdx.x;
