@@ -466,12 +466,23 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
 // correctness assumption. Helps are counted in a device word (MipTimings.prefix_helps).
 // Round 3 and before: the same polls bounded at 0.5 s, then MIP_ERR_TIMEOUT, a ticketed re-issue and a recovery path.
 constexpr uint32_t kPatientPolls = 64;
+constexpr uint32_t kImpatientPolls = 12;  // when more than eight of the words a tile needs are missing (resolve_prefix)
 constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
 
+// A granule of this launch is either PUBLISHED ({sum, tag, count <= kTile}) or, round 5, CLAIMED by a wave that is computing the
+// tile's aggregate on the owner's behalf at this moment (count field all ones, which no tile can count): the other waiting waves
+// then compute other tiles, or look again in a moment, instead of computing the same tile by the dozen.
+constexpr uint32_t kClaimedCount = (1u << kTileCountBits) - 1u;
+static_assert(kTile < kClaimedCount, "the claim marker must not be a count");
 template <class A>
-__device__ __forceinline__ bool granule_ready(const A& a, unsigned long long g) {
+__device__ __forceinline__ bool granule_of_this_launch(const A& a, unsigned long long g) {
   return (((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch;
 }
+template <class A>
+__device__ __forceinline__ bool granule_ready(const A& a, unsigned long long g) {
+  return granule_of_this_launch(a, g) && ((uint32_t)g & kClaimedCount) != kClaimedCount;
+}
+constexpr uint32_t kClaimPolls = 48;  // looks at a claimed tile before the claim is overridden (a help takes one or two of them)
 
 // Σ aggregates of tiles [first, first + count), count <= 64, run by one whole wave: granules where they are published,
 // `help` where they are not. `spread` rotates the order in which missing tiles are taken so that several waiting waves
@@ -483,10 +494,11 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
   //  cold path must fit the hot path's registers)
   unsigned long long pending = count >= 64u ? ~0ull : ((1ull << count) - 1ull);
   const uint32_t rot = spread & 63u;
+  uint32_t idle_looks = 0;
 #pragma nounroll
   while (pending) {  // wave-uniform
     // every pass looks at ALL the tiles still missing with one coalesced load: what other waiting tiles have published since the
-    // last pass is taken from them, and only ONE tile per pass is computed here
+    // last pass is taken from them, and at most ONE tile per pass is computed here
     const bool mine = (pending >> lane) & 1ull;
     unsigned long long g = 0;
     if (mine) g = status_load(&a.status0[first + lane]);
@@ -495,9 +507,35 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
     s += wave_sum(ok ? (uint32_t)(g >> 32) : 0u);
     pending &= ~__ballot(ok);
     if (!pending) break;
-    const unsigned long long turned = rot ? ((pending >> rot) | (pending << (64u - rot))) : pending;
+    // Round 5: a tile that another wave is computing right now (claimed) is left to it; this wave takes one nobody has taken, and
+    // when every missing tile is taken it looks again shortly — a claim is held by a wave that is RUNNING (it is inside `help`),
+    // but nothing may depend on that: after kClaimPolls looks the claim is ignored. (Round 4: every waiting wave computed one
+    // missing tile per pass whoever else was computing it — 45-70 k helps for the 1 950 tiles a scrambled 1 M launch is missing.)
+    const bool claimed = mine && !ok && granule_of_this_launch(a, g);
+    unsigned long long open = pending & ~__ballot(claimed);
+    if (!open) {
+      if (++idle_looks <= kClaimPolls) {
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      open = pending;  // the claimants are not getting there: compute it after all
+    }
+    const unsigned long long turned = rot ? ((open >> rot) | (open << (64u - rot))) : open;
     const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__builtin_ctzll(turned) + rot) & 63u));
     const uint32_t u = first + pick;
+    // take it: the stale (or overridden) granule this wave saw is replaced by the claim, unless somebody got there first
+    const unsigned long long seen = (unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)g, pick) |
+                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(g >> 32), pick) << 32);
+    bool took = true;
+    if (lane == 0u) {
+      unsigned long long expected = seen;
+      const unsigned long long claim = ((unsigned long long)a.epoch << kTileCountBits) | kClaimedCount;
+      took = seen == claim ||  // (an overridden claim: nothing to swap)
+             __hip_atomic_compare_exchange_strong(&a.status0[u], &expected, claim, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    took = __builtin_amdgcn_readfirstlane((int)took) != 0;
+    if (!took) continue;  // published or claimed since the look: the next pass sees which
+    idle_looks = 0;
     const unsigned long long agg = help(u);  // {sum : 32 | count : 32}, wave-uniform
     const uint32_t uc = (uint32_t)agg, us = (uint32_t)(agg >> 32);
     if (lane == 0u) {
@@ -552,6 +590,9 @@ __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile
     // within a group another one), so that together they cover the missing set once instead of all walking it from the bottom —
     // what one publishes the others find (tiles in scrambled order, 1 M instances: 57 k helps and 19 ms per frame before,
     // profiles/r04_selfhelp_any_order.txt for after).
+    // (Round 5 measured a second level — a wave that has walked a whole group publishes the group's total for the others to read —
+    //  on top of the claims: no faster in scrambled order, slower with one tile missing; not kept:
+    //  profiles/r05_selfhelp_claims.txt.)
     const uint32_t rot = (tile * 2654435761u) >> 26;
 #pragma nounroll
     while (open) {
@@ -627,7 +668,10 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
     if (__all(all)) break;
-    if (__builtin_expect(++polls > kPatientPolls, 0)) {  // scalar: wave-uniform
+    // Patience in proportion: a handful of words missing are contemporaries that publish in a moment (the full budget); dozens
+    // missing are workgroups that have not started — waiting for those buys nothing, and every waiting wave waits the same.
+    const uint32_t budget = (uint32_t)__popcll(__ballot(!all)) > 8u ? kImpatientPolls : kPatientPolls;
+    if (__builtin_expect(++polls > budget, 0)) {  // scalar: wave-uniform
       ok = false;
       break;
     }
