@@ -800,6 +800,7 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
     guarded("damaged_helmet_100k_ordered_tiles_serialized", lambda: dict(leg_summary(serialized_leg(
         torch, renderer_amd, make_frame, s2, device, local_rank, stream, args.steps, args.warmup, MIN_SAMPLES, ordered_tiles=True)),
         note="as above (round 3: two launches, 7.55 us)"))
+    guarded("mixed_1m_scrambled_dispatch", lambda: scrambled_dispatch_leg())
     guarded("zero_copy_semaphore_frame", lambda: semaphore_leg())
     guarded("shard_merge_8x336k", lambda: merge_leg(torch, renderer_amd, scene, make_frame, device, local_rank, stream))
     # next-tier rows (not the headline)
@@ -808,16 +809,49 @@ def secondary_single(args, torch, renderer_amd, scene, make_frame, device, local
 
     def mixed_triangles():
         # the mixed 64-mesh scene at 100 k instances: commands from 12 to 23 k triangles; the stage launches both of its large-frame
-        # grids and the ticket-pulling workgroup-per-command one takes the frame (plan_tri_choice_is_block; always the wave-per-command kernel: 0.71 ms)
+        # grids and the range kernel takes the frame (plan_tri_choice_is_ranges; the size-sorted wave-per-command kernel: 0.45-0.47 ms)
         row = triangle_leg(torch, renderer_amd, scene, make_frame, scene.make_scene(3, n=100_000), device, local_rank, False, config=3)
-        row["note"] = ("mixed scene: the largest commands' walk is longer than a wave's share of the frame, so the workgroup-per-command grid is chosen on "
-                       "the device (profiles/r04_triangle_kernel_choice.txt)")
+        row["note"] = ("mixed scene: the largest commands' walk is long against a wave's share of the frame and far above the mean command, so the range "
+                       "kernel (equal ranges of the triangle stream, commands cut between waves) is chosen on the device (profiles/r05_triangle_stage_modes.txt)")
         return row
 
     guarded("triangle_cull_mixed_100k", mixed_triangles)
     guarded("light_draw_lists", lambda: light_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank))
     guarded("culled_views_x4", lambda: views_leg(torch, renderer_amd, scene, make_frame, s3, device, local_rank, stream))
     guarded("skinned_256k", lambda: skinned_leg(torch, renderer_amd, scene, make_frame, None, device, local_rank))
+
+
+def scrambled_dispatch_leg():
+    """The degraded mode, tracked: the frame kernel when workgroups do NOT start in tile order (another tenant of the GPU, RCCL's own
+    kernels beside a shard kernel). The diagnostic build of the library numbers its tiles by a scrambling permutation of the workgroup
+    index (MIP_DEBUG_TILE_ORDER=scramble; never the product), so the tiles that start first miss predecessors that are not even resident
+    and compute their aggregates themselves; serialized launches, HIP events, tools/kbench.py as a child process (the library is chosen at
+    import). Rows: 1 M and 2.5 M instances of the mixed scene, scrambled, and 1 M in order from the same build for comparison."""
+    import re
+    import subprocess
+
+    dbg = os.path.join(ROOT, "renderer_amd", "lib", "libmi_instance_pipeline_dbg.so")
+    if not os.path.exists(dbg):
+        return {"error": "renderer_amd/lib/libmi_instance_pipeline_dbg.so has not been built (__graft_entry__.build())"}
+    rows = {}
+    for label, order in (("scrambled", "scramble"), ("in_order_same_build", None)):
+        env = dict(os.environ)
+        env.pop("MIP_DEBUG_TILE_ORDER", None)
+        if order:
+            env["MIP_DEBUG_TILE_ORDER"] = order
+        sizes = "1000000,2500000" if order else "1000000"
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--configs", ",".join("3" for _ in sizes.split(",")), "--n", sizes,
+                              "--libs", dbg], capture_output=True, text=True, timeout=300, env=env)
+        for line in out.stdout.split("\n"):
+            m = re.search(r"cfg3 n=(\d+)\s+full\s+median\s+([\d.]+) us\s+min\s+([\d.]+)\s+p90\s+([\d.]+)", line)
+            if m:
+                rows[f"{label}_{m.group(1)}"] = {"ms_per_step": float(m.group(2)) * 1e-3, "min_ms": float(m.group(3)) * 1e-3, "p90_ms": float(m.group(4)) * 1e-3}
+        if out.returncode != 0:
+            rows[f"{label}_error"] = (out.stderr or out.stdout)[-400:]
+    rows["note"] = ("diagnostic build, tiles numbered by a scrambled permutation of the workgroup index: what a frame costs when the hardware starts "
+                    "workgroups in an order the launch did not ask for; round 4: 0.30-0.40 ms at 1 M, 1.0-1.1 ms at 2.5 M (host wall clock, "
+                    "profiles/r04_selfhelp_any_order.txt); round 5 (claims): profiles/r05_selfhelp_claims.txt")
+    return rows
 
 
 def semaphore_leg():

@@ -90,8 +90,14 @@ __device__ __forceinline__ unsigned long long help_view_aggregate(uint32_t v, ui
 }
 
 // kGeneral = false: the upload-time census found every instance finite and separable-safe (as for the frame kernel).
+// Compiled for 8 waves per SIMD (round 5): with the bound of 4 the compiler took 96 scalar registers, and the hardware then
+// keeps SIX workgroups on a CU, not the eight its vector registers and LDS allow (found on the per-triangle stage's
+// wave-per-command kernel, which had the same bound and the same 96: profiles/r05_wave_kernel_lifetimes.txt).
+#ifndef MIP_VIEWS_WAVES_PER_SIMD
+#define MIP_VIEWS_WAVES_PER_SIMD 8
+#endif
 template <bool kGeneral>
-__global__ __launch_bounds__(kTile, 4) void mip_cull_views_kernel(const ViewsArgs a) {
+__global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) void mip_cull_views_kernel(const ViewsArgs a) {
   // four words per staged command (instanceCount is the constant 1: the copy-out writes it): 16 KB for the four views, which
   // with the VGPRs lets EIGHT workgroups share a CU (five words: 20.6 KB, seven; the launch is bound by tiles in flight x
   // a tile's latency, not by bytes)
