@@ -506,8 +506,8 @@ int32_t mip_signal_external(MipContext* ctx, MipExternalSemaphore* semaphore, ui
 int32_t mip_release_external_semaphore(MipContext* ctx, MipExternalSemaphore* semaphore);
 
 const char* mip_last_error(const MipContext* ctx);
-int32_t mip_get_timings(MipContext* ctx, MipTimings* out);
-int32_t mip_reset_timings(MipContext* ctx);
+int32_t mip_get_timings(MipContext* ctx, MipTimings* out);  /* touches the device: a blocking 4-byte read of the help counter */
+int32_t mip_reset_timings(MipContext* ctx);                /* (the same read: prefix_helps counts from here on, also with frames in flight) */
 
 /* Number of instances currently resident (set by mip_set_instances*). */
 uint32_t mip_instance_count(const MipContext* ctx);

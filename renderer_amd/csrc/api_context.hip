@@ -543,9 +543,9 @@ const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "nul
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out) {
   if (!ctx || !out) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;
-  uint32_t helps = 0;  // the device adds (kernels that are in flight may still be adding), the host only reads
+  uint32_t helps = 0;  // the device adds (kernels that are in flight may still be adding), the host only reads: a blocking 4-byte copy
   MIP_HIP(ctx, hipMemcpy(&helps, ctx->d_help, 4, hipMemcpyDeviceToHost));
-  ctx->timings.prefix_helps = helps;
+  ctx->timings.prefix_helps = helps - ctx->help_base;  // (wrapping difference: cumulative since create or mip_reset_timings)
   *out = ctx->timings;
   return MIP_OK;
 }
@@ -553,8 +553,11 @@ int32_t mip_get_timings(MipContext* ctx, MipTimings* out) {
 int32_t mip_reset_timings(MipContext* ctx) {
   if (!ctx) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;
-  // (the help counter is written by kernels that may be in flight: it is cleared only when nothing is)
-  if (!ctx->pending_async) MIP_HIP(ctx, hipMemset(ctx->d_help, 0, 4));
+  // the help counter is written by kernels that may be in flight: the device word is never cleared, the host keeps the value it
+  // had at the reset (round 4 cleared it only when nothing was in flight, and reported the old count beside freshly reset fields otherwise)
+  uint32_t helps = 0;
+  MIP_HIP(ctx, hipMemcpy(&helps, ctx->d_help, 4, hipMemcpyDeviceToHost));
+  ctx->help_base = helps;
   ctx->timings = MipTimings{};
   return MIP_OK;
 }

@@ -133,6 +133,7 @@ struct MipContext {
   uint32_t* d_census = nullptr;
   uint32_t* h_error = nullptr;  // pinned, device-visible: error words [0, kErrWords)
   uint32_t* d_help = nullptr;   // device memory: helped tile aggregates (MipTimings.prefix_helps); read back by mip_get_timings
+  uint32_t help_base = 0;       // its value at the last mip_reset_timings
   uint32_t* d_error = nullptr;  // device alias of h_error
   uint32_t carried_error_bits = 0;  // error bits a synchronous call saw while asynchronous work was in flight: reported then AND by the next mip_wait
   // staging for MIP_OUT_HOST

@@ -155,8 +155,15 @@ class DrawListExchange:
         # skipped the repair's all-gather would leave its peers blocked in it for good (round-3 advisor finding).
         overflow = False
         if in_flight:
-            counts, _ = self.counts()
-            overflow = int(counts.max()) > self.capacity
+            # the gathered headers are read back through the device: after a FATAL device error that read may itself fail or
+            # return garbage (a count above every shard's size) — then there is nothing to repair, and the error that counts is
+            # the one mip_wait reported (round-4 advisor finding)
+            try:
+                counts, _ = self.counts()
+                largest = int(counts.max())
+            except Exception:  # noqa: BLE001 (torch raises RuntimeError subclasses on a dead device)
+                raise err from None
+            overflow = self.capacity < largest <= self.n_max
         if not overflow:
             raise err
         if in_flight != 1:
