@@ -163,8 +163,31 @@ for seed in range(first, first + seeds):
         vertices, indices = ra.scene.make_geometry(t["meshes"], ordering=str(rng.choice(["rows", "strips", "shuffled"])))
         pv = oracle.camera_pv(cam_pos=tuple(float(x) for x in rng.normal(0, 3, 3)), aspect=float(rng.uniform(0.7, 2.5)),
                               fovy_degrees=float(rng.uniform(30, 110)))
-        r = oracle.run(t["pos"], t["rot"], t["scale"], t["mesh_id"], t["meshes"], t["planes"], t["cam_pos"], threads=8)
-        cap = r["draw_index_total"] + 3
+        # round 5: which kernel of the stage takes the frame is part of the rotation (read by mip_create): the range kernel with one range
+        # per wave or with short ranges pulled from the counter, the large-frame pairing (sort kernels, both grids) chosen on the device or
+        # forced either way, the round-4 kernels; an index base that is no multiple of 3; index counts that are no multiple of 3
+        for k in ("MIP_TUNE_TRI_RANGE_SLOTS", "MIP_TUNE_TRI_BLOCK_MAX", "MIP_TUNE_TRI_CHOICE", "MIP_TUNE_TRI_CHUNKS_FROM"):
+            os.environ.pop(k, None)
+        mode = int(rng.integers(0, 8))
+        if mode in (1, 2, 5):
+            os.environ["MIP_TUNE_TRI_RANGE_SLOTS"] = str(int(rng.choice([256, 512, 1024])))
+        if mode in (3, 4, 5, 6):
+            os.environ["MIP_TUNE_TRI_BLOCK_MAX"] = "0"
+            if mode in (4, 5):
+                os.environ["MIP_TUNE_TRI_CHOICE"] = "block"   # the range kernel's grid
+            elif mode == 6:
+                os.environ["MIP_TUNE_TRI_CHOICE"] = "waves"
+        if mode == 7:
+            os.environ["MIP_TUNE_TRI_CHUNKS_FROM"] = "4294967295"
+        index_base = int(rng.choice([0, 0, 5, 7, 3000001]))
+        if rng.random() < 0.3:
+            t["meshes"] = t["meshes"].copy()
+            for k in range(len(t["meshes"])):
+                for lod in range(int(t["meshes"]["n_lods"][k])):
+                    if rng.random() < 0.3 and t["meshes"]["index_len"][k][lod] > 4:
+                        t["meshes"]["index_len"][k][lod] -= int(rng.integers(1, 3))
+        r = oracle.run(t["pos"], t["rot"], t["scale"], t["mesh_id"], t["meshes"], t["planes"], t["cam_pos"], first_index_base=index_base, threads=8)
+        cap = index_base + r["draw_index_total"] + 3
         wc, wo, _ = oracle.cull_all_triangles(r, t["pos"], t["mesh_id"], t["meshes"], t["cam_pos"], pv, vertices, indices, out_capacity=cap)
         with ra.InstancePipeline(max_instances=nt, max_meshes=64) as p:
             p.set_mesh_table(t["meshes"])
@@ -175,13 +198,13 @@ for seed in range(first, first + seeds):
             scal = torch.zeros(8, dtype=torch.int32, device=dev)
             out = torch.full((cap,), -1, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
-            p.run_device(make_frame(t["planes"], t["cam_pos"], pv=pv), model=model.data_ptr(), draw_cmds=cmds.data_ptr(),
+            p.run_device(make_frame(t["planes"], t["cam_pos"], first_index_base=index_base, pv=pv), model=model.data_ptr(), draw_cmds=cmds.data_ptr(),
                          draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, culled_index_buffer=out.data_ptr(),
                          culled_index_capacity=cap)
             count = int(scal[0].item())
             if not (count == len(wc) and cmds[:count].cpu().numpy().tobytes() == wc.tobytes()
                     and np.array_equal(out.cpu().numpy().view(np.uint32), wo)):
-                fail(seed, f"triangle stage cfg={cfg} n={nt}")
+                fail(seed, f"triangle stage cfg={cfg} n={nt} mode={mode} index_base={index_base} env={ {k: v for k, v in os.environ.items() if k.startswith('MIP_TUNE_TRI')} }")
     done += 1
     if done % 25 == 0:
         print(f"{done} seeds ok (last: n={n})", flush=True)
