@@ -213,6 +213,53 @@ def test_triangle_cull_index_base_and_index_counts_that_are_no_multiple_of_three
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want_out)
 
 
+@pytest.mark.parametrize("large_frame_path", [False, True])
+def test_triangle_stage_with_frames_in_flight(ra, oracle_mod, monkeypatch, large_frame_path):
+    """Two frame slots, two cameras, asynchronous frames alternating between them: every slot owns its scratch (command list, final
+    counts, range map and granules, size-class table and ticket counter), so the culled streams of frames that overlap on the device
+    are each the oracle's — with the range kernel alone and with the large-frame pairing (sort kernels + both grids)."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    if large_frame_path:
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+    s = ra.scene.make_scene(3, n=6000)
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    pv = ra.scene.default_pv()
+    cams = [np.array(c, np.float32) for c in ((0, 1, 2), (5, 1, -20))]
+    planes = [s["planes"], oracle_mod.project_camera(cams[1], (0.0, 0.0, 0.0, 1.0))]
+    wants = []
+    for k in range(2):
+        r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], planes[k], cams[k], threads=8)
+        cap = r["draw_index_total"] + 3
+        wc, wo, _ = oracle_mod.cull_all_triangles(r, s["pos"], s["mesh_id"], s["meshes"], cams[k], pv, vertices, indices, out_capacity=cap)
+        wants.append((cap, wc, wo))
+    dev = torch.device("cuda", 0)
+    n = s["n"]
+    with ra.InstancePipeline(max_instances=n, max_meshes=len(s["meshes"]), frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_geometry(vertices, indices)
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        bufs = []
+        for k in range(2):
+            bufs.append(dict(model=torch.zeros((n, 16), dtype=torch.float32, device=dev), cmds=torch.zeros((n, 5), dtype=torch.int32, device=dev),
+                             scal=torch.zeros(8, dtype=torch.int32, device=dev), out=torch.full((wants[k][0],), -1, dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+        for rep in range(6):  # 12 asynchronous frames rotating over the two slots
+            for k in range(2):
+                b = bufs[k]
+                p.run_device(make_frame(planes[k], cams[k], pv=pv), model=b["model"].data_ptr(), draw_cmds=b["cmds"].data_ptr(), draw_count=b["scal"].data_ptr(),
+                             draw_index_total=b["scal"].data_ptr() + 4, culled_index_buffer=b["out"].data_ptr(), culled_index_capacity=wants[k][0], async_=True)
+        p.wait()
+        for k in range(2):
+            b = bufs[k]
+            count = int(b["scal"][0].item())
+            got = b["cmds"][:count].cpu().numpy().view(np.uint32).reshape(-1).view(ra.DRAW_CMD_DTYPE)
+            assert count == len(wants[k][1]) and got.tobytes() == wants[k][1].tobytes(), k
+            assert np.array_equal(b["out"].cpu().numpy().view(np.uint32), wants[k][2]), k
+
+
 def test_triangle_cull_with_non_finite_positions(ra, oracle_mod):
     """Positions that are not finite switch off the affine shortcut (0 * inf is not 0): the literal
     mat4 * vec4 chain must then reproduce the oracle, including for instances with ordinary matrices."""
