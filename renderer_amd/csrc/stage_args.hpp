@@ -85,6 +85,8 @@ struct TrianglePartsArgs {
 };
 
 // Round 5: the stage as equal RANGES of the frame's triangle stream, one per wave (triangle_kernels.hpp, mip_triangle_cull_ranges_kernel).
+// ("chunk" in identifiers — TriangleChunkArgs, chunk_walk, TriangleKernel::chunks, MIP_TUNE_TRI_CHUNKS_FROM — is what the first build of this
+// kernel called a range.)
 struct TriangleChunkArgs {
   TriangleArgs t;                      // (index_total, max_lod_tris, pull_tickets unused; ticket: zeroed by the host)
   uint32_t* range_first_cmd;           // [ranges_cap]: the first command that owns a slot at or behind the range's first slot
