@@ -302,7 +302,9 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         // 32-bit firstIndex can number, and by the largest command times the instances.
         unsigned long long tris = out->culled_index_capacity / 3ull;
         if (tris > 0xffffffffull / 3ull) tris = 0xffffffffull / 3ull;
-        if (tris > (unsigned long long)n * ctx->max_lod_tris) tris = (unsigned long long)n * ctx->max_lod_tris;
+        // (a command owns floor(indexCount / 3) slots, but the slots are numbered by the running sum of indexCount / 3: index counts that
+        //  are no multiple of 3 push later commands up to 2/3 of a slot each — hence the + 1 per instance)
+        if (tris > (unsigned long long)n * (ctx->max_lod_tris + 1ull)) tris = (unsigned long long)n * (ctx->max_lod_tris + 1ull);
         size_t need = (size_t)(tris / ctx->tri_ticket_slots) + 2;
         if (need < (size_t)plan.tri_blocks * 4u + 1u) need = (size_t)plan.tri_blocks * 4u + 1u;
         if (sl.chunks_cap < need) {

@@ -260,6 +260,32 @@ def test_triangle_stage_with_frames_in_flight(ra, oracle_mod, monkeypatch, large
             assert np.array_equal(b["out"].cpu().numpy().view(np.uint32), wants[k][2]), k
 
 
+def test_ranges_of_a_stream_whose_every_command_has_two_indices_too_many(ra, oracle_mod, monkeypatch):
+    """One mesh whose index counts are 3 k + 2, every instance visible, an index buffer far larger than the frame needs: the stream is
+    then LONGER in slots than instances x triangles of the largest command (the slots are numbered by the running sum of indexCount / 3,
+    and every command pushes the later ones up by 2/3 of a slot) — the bound the host sizes the range map by has to allow for that, or
+    the last ranges of the frame are never walked."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    monkeypatch.setenv("MIP_TUNE_TRI_RANGE_SLOTS", "256")
+    s = ra.scene.make_scene(2, n=3000, all_visible=True)
+    vertices, indices = ra.scene.make_geometry(s["meshes"])
+    meshes = s["meshes"].copy()
+    for lod in range(int(meshes["n_lods"][0])):
+        meshes["index_len"][0][lod] = meshes["index_len"][0][lod] // 3 * 3 - 1   # 3 k + 2
+    s["meshes"] = meshes
+    pv = ra.scene.default_pv()
+    r = oracle_mod.run(s["pos"], s["rot"], s["scale"], s["mesh_id"], s["meshes"], s["planes"], s["cam_pos"], threads=8)
+    capacity = 2 * r["draw_index_total"] + 64
+    want_cmds, want_out, _ = oracle_mod.cull_all_triangles(r, s["pos"], s["mesh_id"], s["meshes"], s["cam_pos"], pv, vertices, indices, out_capacity=capacity)
+    got_cmds, count, total, got_out = _run_gpu(ra, s, vertices, indices, pv, capacity)
+    assert count == len(want_cmds) and total == r["draw_index_total"]
+    assert got_cmds.tobytes() == want_cmds.tobytes()
+    assert np.array_equal(got_out, want_out)
+
+
 def test_triangle_cull_with_non_finite_positions(ra, oracle_mod):
     """Positions that are not finite switch off the affine shortcut (0 * inf is not 0): the literal
     mat4 * vec4 chain must then reproduce the oracle, including for instances with ordinary matrices."""
