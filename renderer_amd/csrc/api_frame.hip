@@ -282,6 +282,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       t.src_index_offset = sl.d_tmp_src;
       t.model = (const float4*)out->model;
       t.vertices = ctx->d_vertices;
+      t.vertex_bytes = (unsigned long long)ctx->n_vertices * 12ull;
       t.indices = ctx->d_indices;
       t.out_indices = (uint32_t*)out->culled_index_buffer;
       t.capacity = out->culled_index_capacity;

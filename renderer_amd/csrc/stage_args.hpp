@@ -28,6 +28,7 @@ struct TriangleArgs {
   const uint32_t* src_index_offset;
   const float4* model;            // n x mat4 of the same frame
   const float* vertices;          // consolidated positions, packed vec3
+  unsigned long long vertex_bytes; // their size (the walk reads them through a bounded descriptor)
   const uint32_t* indices;        // consolidated indices
   uint32_t* out_indices;          // culled index stream (uvec3 out_index_buffer[])
   unsigned long long capacity;    // in indices

@@ -195,39 +195,52 @@ constexpr uint32_t kTriDropOffset = 0x80000000u;  // beyond every region: the st
 #define MIP_TRI_STORE_AUX 0
 #endif
 
+// Addresses: the index triples and the positions are read through buffer descriptors too — over the command's own index range and
+// over the vertex buffer from the mesh's vertex_offset on — with 32-bit byte offsets: `t * 12` advances by one add per step, a
+// corner's `i * 12` is a shift and a shift-add. (Round 4's loop built a 64-bit address per load: four v_mad_u64_u32, three
+// v_lshl_add_u64 and a v_mul_lo_u32 per step — quarter-rate instructions, ~27 of the step's ~190 issue slots.) A triangle number
+// beyond the command reads zeros (vertex 0 of the mesh), so idle lanes need no clamp.
+// (Written as the two full-rate instructions it is: the compiler folds `(i << 3) + (i << 2)` back into a quarter-rate v_mul_lo_u32.)
+__device__ __forceinline__ uint32_t times12(uint32_t i) {
+  uint32_t r;
+  asm("v_lshlrev_b32 %0, 2, %1\n\tv_lshl_add_u32 %0, %1, 3, %0" : "=&v"(r) : "v"(i));
+  return r;
+}
+
 template <bool kAffine, bool kDirect>
 __device__ __forceinline__ uint32_t chunk_walk(const TriangleArgs& a, const ChunkCmd& m, const float (&model)[16], const float (&pv)[16],
                                                uint32_t t_begin, uint32_t t_end, bool fits, size_t dst_tri, unsigned long long* masks, uint32_t lane) {
-  const uint32_t* tri_indices = a.indices + (size_t)m.src_tri * 3;
+  const unsigned long long index_bytes = (unsigned long long)m.n_tris * 12ull;
+  const __amdgpu_buffer_rsrc_t idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.indices) + (size_t)m.src_tri * 3, 0,
+      (int)(index_bytes < kTriRegionMax ? (uint32_t)index_bytes : kTriRegionMax), 0x00020000);
+  const long long vertex_first = (long long)m.vertex_offset * 12ll;  // bytes; the positions of this mesh start here
+  const unsigned long long vertex_left = vertex_first < (long long)a.vertex_bytes ? a.vertex_bytes - (unsigned long long)vertex_first : 0ull;
+  const __amdgpu_buffer_rsrc_t vtx = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.vertices)) + vertex_first, 0,
+      (int)(vertex_left < kTriRegionMax ? (uint32_t)vertex_left : kTriRegionMax), 0x00020000);
   const unsigned long long region = (unsigned long long)(t_end - t_begin) * 12ull;
   const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(a.out_indices + dst_tri * 3, 0,
       (int)(kDirect && fits ? (region < kTriRegionMax ? (uint32_t)region : kTriRegionMax) : 0u), 0x00020000);
   uint32_t survivors = 0, step = 0;
-  uint32_t n0, n1, n2;  // idle lanes re-read the segment's last triangle: in bounds
-  {
-    const uint32_t tn = t_begin + lane < t_end ? t_begin + lane : t_end - 1u;
-    const uint32_t* ip = tri_indices + (size_t)tn * 3;
-    n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
-  }
+  uint32_t t_offset = times12(t_begin + lane);  // byte offset of this lane's triangle of the step in the command's index range
+  tri_u32x3 next = __builtin_amdgcn_raw_buffer_load_b96(idx, (int)t_offset, 0, 0);
   tri_u32x3 q = {0u, 0u, 0u};          // the previous step's survivors, stored behind this step's gathers
   uint32_t q_offset = kTriDropOffset;
   for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u, ++step) {
-    const uint32_t t = t0 + lane;
-    const bool valid = t < t_end;
-    const uint32_t i0 = n0, i1 = n1, i2 = n2;
-    float v[9];
-    triangle_fetch(a.vertices, (long long)m.vertex_offset, i0, i1, i2, v);
+    const bool valid = t0 + lane < t_end;
+    const tri_u32x3 i = next;
+    const tri_u32x3 v0 = __builtin_amdgcn_raw_buffer_load_b96(vtx, (int)times12(i.x), 0, 0);
+    const tri_u32x3 v1 = __builtin_amdgcn_raw_buffer_load_b96(vtx, (int)times12(i.y), 0, 0);
+    const tri_u32x3 v2 = __builtin_amdgcn_raw_buffer_load_b96(vtx, (int)times12(i.z), 0, 0);
     if constexpr (kDirect) __builtin_amdgcn_raw_buffer_store_b96(q, out, (int)q_offset, 0, MIP_TRI_STORE_AUX);
-    {
-      const uint32_t tn = t + 64u < t_end ? t + 64u : t_end - 1u;
-      const uint32_t* ip = tri_indices + (size_t)tn * 3;
-      n0 = ip[0]; n1 = ip[1]; n2 = ip[2];
-    }
+    t_offset += 768u;
+    next = __builtin_amdgcn_raw_buffer_load_b96(idx, (int)t_offset, 0, 0);  // (beyond the command: zeros)
+    const float v[9] = {__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v1.x), __uint_as_float(v1.y),
+                        __uint_as_float(v1.z), __uint_as_float(v2.x), __uint_as_float(v2.y), __uint_as_float(v2.z)};
     const bool keep = !triangle_test<kAffine>(model, pv, v) && valid;
     const unsigned long long mask = __ballot(keep);
     if constexpr (kDirect) {
-      q = tri_u32x3{i0, i1, i2};
-      q_offset = keep ? (survivors + lanes_below(mask)) * 12u : kTriDropOffset;
+      q = i;
+      q_offset = keep ? times12(survivors + lanes_below(mask)) : kTriDropOffset;
     } else {
       if (lane == 0u) masks[step] = mask;  // (the range kernel sizes the buffer for its longest range)
     }
