@@ -493,7 +493,9 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
   // (c and s are wave-uniform, and so is the set of tiles still to be summed; nothing per lane stays alive across a help: the
   //  cold path must fit the hot path's registers)
   unsigned long long pending = count >= 64u ? ~0ull : ((1ull << count) - 1ull);
-  const uint32_t rot = spread & 63u;
+  // where this wave starts among the tiles: spread over the `count` tiles there are (a rotation taken modulo 64 sent every wave
+  // whose number fell beyond a short run back to its first tile)
+  const uint32_t rot = count >= 64u ? (spread & 63u) : (count ? spread % count : 0u);
   uint32_t idle_looks = 0;
 #pragma nounroll
   while (pending) {  // wave-uniform
@@ -591,9 +593,12 @@ __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile
     // what one publishes the others find (tiles in scrambled order, 1 M instances: 57 k helps and 19 ms per frame before,
     // profiles/r04_selfhelp_any_order.txt for after).
     // (Round 5 measured a second level — a wave that has walked a whole group publishes the group's total for the others to read —
-    //  on top of the claims: no faster in scrambled order, slower with one tile missing; not kept:
+    //  and four groups' granules loaded per round trip, both on top of the claims: no faster in scrambled order; not kept:
     //  profiles/r05_selfhelp_claims.txt.)
-    const uint32_t rot = (tile * 2654435761u) >> 26;
+    // ... uniformly over the groups of this window (round 4 took 6 hash bits as they came: with 30 earlier groups more than half
+    // of the waves started at group 0 and walked upwards together — a chain of 30 visits instead of one round of helps)
+    const uint32_t span = group - gb < 64u ? group - gb : 64u;
+    const uint32_t rot = ((tile * 2654435761u) >> 12) % span;
 #pragma nounroll
     while (open) {
       const unsigned long long turned = rot ? ((open >> rot) | (open << (64u - rot))) : open;
