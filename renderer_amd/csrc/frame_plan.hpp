@@ -179,14 +179,17 @@ inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
     return p;
   }
   p.n_tiles = plan_tiles_for(n);
-  // order (instance_kernel.hpp): commands-first while the launch is less than about two generations of workgroups
-  // (8 per CU: every tile is ramp or tail), stores-first once there is a steady state. Measured on MI355X
-  // (profiles/r02_order*.txt): order 3 ahead below ~0.8 M instances, order 1 ahead from ~1 M. A frame that streams no
-  // per-instance output (no matrices, TLAS rows or boxes: cull + commands only, 41 instead of 105 MB at 1 M) has no store
-  // stream for the stores-first order to keep fed, and commands-first stays ahead longer: 1 M 14.4 vs 15.7 us, even at
+  // order (instance_kernel.hpp): commands-first while the launch is ONE generation of workgroups — every tile resident at once
+  // (8 workgroups per CU; 5 for the kernel that carries the fall-back arithmetic tiers) —, stores-first beyond. Round 5 measured the
+  // crossover point by point (profiles/r05_order_crossover.txt): the commands-first order has a cliff exactly there — 524 288
+  // instances = 2 048 tiles 9.95 us, 540 000 12.0 us — while the stores-first order grows smoothly (10.4 -> 11.0), and stays ahead from
+  // there on (600 k 11.7 vs 12.8, 786 k 14.6 vs 14.9, 917 k 16.9 vs 17.7). (Rounds 2-4 switched at 14 tiles per CU = 917 k instances.)
+  // A frame that streams no per-instance output (no matrices, TLAS rows or boxes: cull + commands only, 41 instead of 105 MB at 1 M)
+  // has no store stream for the stores-first order to keep fed, and commands-first stays ahead longer: 1 M 14.4 vs 15.7 us, even at
   // 1.25-1.5 M, behind from 1.75 M (profiles/r04_order_for_command_only_frames.txt).
   const bool streams = rq.model || rq.tlas || rq.aabb;
-  p.order = p.n_tiles <= st.cu_count * (streams ? 14u : 17u) ? 3 : 1;
+  const bool general_kernel = rq.skinned || st.nonfinite || st.force_general;
+  p.order = p.n_tiles <= st.cu_count * (streams ? (general_kernel ? 5u : 8u) : 17u) ? 3 : 1;
   if (st.force_order == 1 || st.force_order == 3) p.order = st.force_order;
   p.box_override = rq.skinned;
   p.general = rq.skinned || st.nonfinite || st.force_general;  // a per-instance box may be non-finite

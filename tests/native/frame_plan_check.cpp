@@ -54,7 +54,8 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
   CHECK(p.n_tiles == (st.n + 255u) / 256u, "one tile per 256 instances");
   CHECK(p.order == 1 || p.order == 3, "order %d", p.order);
   if (st.force_order) CHECK(p.order == st.force_order, "forced order");
-  else CHECK((p.order == 3) == (p.n_tiles <= st.cu_count * ((rq.model || rq.tlas || rq.aabb) ? 14u : 17u)), "order by launch size and by whether a per-instance stream is written");
+  else CHECK((p.order == 3) == (p.n_tiles <= st.cu_count * ((rq.model || rq.tlas || rq.aabb) ? (p.general ? 5u : 8u) : 17u)),
+             "order: commands-first while the launch is one generation of workgroups (or, without a per-instance stream, up to 17 tiles per CU)");
   CHECK(p.group_shift >= 4 && p.group_shift <= 6 && ((p.n_tiles + (1u << p.group_shift) - 1u) >> p.group_shift) <= (st.max_instances / 256u + 16u) / 16u + 1u,
         "groups fit the prefix state sized at create (smallest group: 16 tiles)");
   CHECK(p.box_override == rq.skinned, "box override <=> skinned");
@@ -140,7 +141,7 @@ static void check_tri_choice() {
 
 int main() {
   check_tri_choice();
-  const uint32_t sizes[] = {0u, 1u, 257u, 768u, 1025u, 3073u, 65537u, 917504u, 917505u, 1114112u, 1114113u, 0x3fffffffu};  // both order thresholds at 256 CUs
+  const uint32_t sizes[] = {0u, 1u, 257u, 768u, 1025u, 3073u, 65537u, 327680u, 327681u, 524288u, 524289u, 1114112u, 1114113u, 0x3fffffffu};  // the order thresholds at 256 CUs
   const uint32_t flag_sets[] = {MIP_OUT_HOST, MIP_OUT_DEVICE, MIP_OUT_DEVICE | MIP_OUT_ASYNC, MIP_OUT_ASYNC, MIP_OUT_DEVICE | MIP_OUT_WIRE,
                                 MIP_OUT_DEVICE | MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED, MIP_OUT_DEVICE | MIP_OUT_WIRE_PACKED, MIP_OUT_WIRE,
                                 MIP_OUT_DEVICE | MIP_OUT_ASYNC | MIP_OUT_WIRE | MIP_OUT_WIRE_PACKED};
