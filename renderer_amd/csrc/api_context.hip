@@ -228,6 +228,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     }
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_MAX")) ctx->tri_block_max = (uint32_t)std::strtoul(env, nullptr, 10);
     if (const char* env = std::getenv("MIP_TUNE_TRI_PARTS_MAX")) ctx->tri_parts_max = (uint32_t)std::strtoul(env, nullptr, 10);
+    if (const char* env = std::getenv("MIP_TUNE_TRI_RECOMPACT_LAUNCHES")) ctx->tri_recompact_three_launches = std::atoi(env) == 3;
     if (const char* env = std::getenv("MIP_TUNE_TRI_RANGE_SLOTS")) {
       const uint32_t v = (uint32_t)std::strtoul(env, nullptr, 10) / 64u * 64u;
       if (v >= 256u && v <= 8192u) ctx->tri_ticket_slots = v;

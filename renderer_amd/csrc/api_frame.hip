@@ -225,7 +225,11 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
     // indexCount there and the final compaction lands in the caller's buffers
     if (!sl.d_tmp_cmds) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_cmds, cap * 20));
     if (!sl.d_tmp_src) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_src, cap * 4));
-    if (!sl.d_tmp_blocks) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_blocks, (cap / 1024 + 1) * 4));
+    if (!sl.d_tmp_blocks) {  // one granule per 1024 commands (the one-launch re-compaction; the round-4 form uses the first half as words)
+      MIP_HIP(ctx, hipMalloc(&sl.d_tmp_blocks, (cap / 1024 + 1) * 8));
+      MIP_HIP(ctx, hipMemsetAsync(sl.d_tmp_blocks, 0, (cap / 1024 + 1) * 8, stream));
+      sl.recompact_epoch = 0;
+    }
     if (!sl.d_tmp_final) MIP_HIP(ctx, hipMalloc(&sl.d_tmp_final, cap * 4));
     a.cmds = sl.d_tmp_cmds;
     a.draw_count = sl.d_scalars + 2;
@@ -292,8 +296,11 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       t.ticket = sl.d_scalars + 3;
       t.geometry_finite = ctx->geometry_finite ? 1u : 0u;
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
+      uint32_t* zero_words = nullptr;  // counters of the stage that the re-compaction clears for the slot's next frame
+      uint32_t n_zero = 0;
+      if (plan.tri != mip::TriangleKernel::chunks) sl.tri_ticket_clean = false;  // (the round-4 kernels leave the shared ticket word as it ends)
       if (plan.tri == mip::TriangleKernel::chunks || plan.tri == mip::TriangleKernel::sorted) {
-        const bool either = plan.tri == mip::TriangleKernel::sorted;  // both grids are launched and one returns at once (tri_not_this_grid)
+        const bool either = plan.tri == mip::TriangleKernel::sorted;  // one grid, either decomposition, chosen on the device (mip_triangle_stage_kernel)
         t.first_index_base = frame->first_index_base;
         t.max_lod_tris = ctx->max_lod_tris;
         if (ctx->tri_force_choice) t.max_lod_tris = ctx->tri_force_choice == 1 ? 0x7fffffffu : 0u;  // tests / A-B runs: ranges | waves
@@ -328,17 +335,23 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         if (either) {
           // the commands by descending size class for the wave-per-command grid; one clear covers histogram, arrival counter and ticket
           if (!sl.d_tri_order) MIP_HIP(ctx, hipMalloc(&sl.d_tri_order, cap * 4));
-          if (!sl.d_tri_sort) MIP_HIP(ctx, hipMalloc(&sl.d_tri_sort, mip::kSortWords * 4));
-          MIP_HIP(ctx, hipMemsetAsync(sl.d_tri_sort, 0, mip::kSortWords * 4, stream));
+          if (!sl.d_tri_sort) {
+            MIP_HIP(ctx, hipMalloc(&sl.d_tri_sort, mip::kSortWords * 4));
+            sl.tri_sort_clean = false;
+          }
+          // (the re-compaction at the end of a frame clears these counters for the slot's next frame: no clear per frame)
+          if (!sl.tri_sort_clean) MIP_HIP(ctx, hipMemsetAsync(sl.d_tri_sort, 0, mip::kSortWords * 4, stream));
+          sl.tri_sort_clean = false;  // until this frame's re-compaction has been enqueued
+          zero_words = sl.d_tri_sort;
+          n_zero = mip::kSortWords;
           t.sort_info = sl.d_tri_sort;
           t.ticket = sl.d_tri_sort + mip::kSortTicket;
           t.final_index_count = sl.d_tmp_final;
-          mip::TriangleArgs w = t;
-          w.choice_mode = 2u;
-          w.order = sl.d_tri_order;
-          mip::launch_triangle_sort(plan.tri_map_blocks, stream, w, sl.d_tri_order);
         } else {
-          MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
+          if (!sl.tri_ticket_clean) MIP_HIP(ctx, hipMemsetAsync(t.ticket, 0, 4, stream));
+          sl.tri_ticket_clean = false;
+          zero_words = t.ticket;
+          n_zero = 1;
         }
         mip::TriangleChunkArgs ca{};
         ca.t = t;
@@ -355,12 +368,11 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         if (const char* env = std::getenv("MIP_DEBUG_TILE_ORDER")) ca.debug_reverse = std::strcmp(env, "reverse") == 0 ? 1u : 0u;
         if (const char* env = std::getenv("MIP_DEBUG_SKIP_PART")) ca.debug_skip_part = (uint32_t)std::atoi(env) % 16u + 1u;
 #endif
-        mip::launch_triangle_cull_chunks(plan.tri_map_blocks, plan.tri_blocks, stream, ca);
         if (either) {
-          mip::TriangleArgs w = t;
-          w.choice_mode = 2u;
-          w.order = sl.d_tri_order;
-          mip::launch_triangle_cull_waves(plan.tri_wave_blocks, stream, w);
+          ca.t.order = sl.d_tri_order;  // (the wave-per-command decomposition's; the range decomposition does not look at it)
+          mip::launch_triangle_stage(plan.tri_map_blocks, plan.tri_blocks, stream, ca);
+        } else {
+          mip::launch_triangle_cull_chunks(plan.tri_map_blocks, plan.tri_blocks, stream, ca);
         }
       } else if (plan.tri == mip::TriangleKernel::parts) {
         const size_t cap_cmds = ctx->max_instances < ctx->tri_parts_max ? cap : ctx->tri_parts_max;
@@ -410,6 +422,8 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;
+        r.zero_words = zero_words;
+        r.n_zero = n_zero;
         mip::launch_recompact(stream, r);
       } else {
         mip::RecompactWideArgs r{};
@@ -418,11 +432,29 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         r.in_count = sl.d_scalars + 2;
         r.out_cmds = (uint32_t*)out->draw_cmds;
         r.out_count = out->draw_count;
-        r.block_base = sl.d_tmp_blocks;
+        r.block_base = (uint32_t*)sl.d_tmp_blocks;
         r.n_blocks = plan.recompact_blocks;
+        if (!ctx->tri_recompact_three_launches) {  // one launch (round 5); MIP_TUNE_TRI_RECOMPACT_LAUNCHES=3: round 4's count / scan / scatter
+          if (sl.recompact_epoch == 0xffffffffu) {  // tag wrap: start over on cleared granules
+            MIP_HIP(ctx, hipMemsetAsync(sl.d_tmp_blocks, 0, (cap / 1024 + 1) * 8, stream));
+            sl.recompact_epoch = 0;
+          }
+          r.block_status = sl.d_tmp_blocks;
+          r.epoch = ++sl.recompact_epoch;
+          r.help_counter = ctx->d_help;
+          r.zero_words = zero_words;
+          r.n_zero = n_zero;
+#ifdef MIP_DEBUG_STAMPS
+          r.debug_skip = std::getenv("MIP_DEBUG_SKIP_PART") ? 1u : 0u;
+#endif
+        }
         mip::launch_recompact_wide(stream, r);
       }
       MIP_HIP(ctx, hipGetLastError());
+      // the counters are cleared by the re-compaction that has just been enqueued (not by the three-launch form)
+      const bool cleared = n_zero != 0u && (plan.recompact == mip::Recompact::single || !ctx->tri_recompact_three_launches);
+      if (zero_words == sl.d_tri_sort && zero_words) sl.tri_sort_clean = cleared;
+      else if (zero_words) sl.tri_ticket_clean = cleared;
     }
     if (timing) MIP_HIP(ctx, hipEventRecord(ctx->ev1, stream));
   }

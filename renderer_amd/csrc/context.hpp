@@ -39,7 +39,10 @@ struct MipContext {
     uint32_t* d_scalars = nullptr;           // [0] draw_count, [1] index_total (host-output runs), [2] pre-triangle count, [3] command ticket
     uint32_t* d_tmp_cmds = nullptr;          // per-triangle stage: the instance kernel's list before re-compaction
     uint32_t* d_tmp_src = nullptr;           //                     and each command's source index offset
-    uint32_t* d_tmp_blocks = nullptr;        //                     re-compaction of large frames: one word per 1024 commands
+    unsigned long long* d_tmp_blocks = nullptr;  //                 re-compaction of large frames: one granule per 1024 commands
+    uint32_t recompact_epoch = 0;            //                     tag of the last one-launch re-compaction on this slot
+    bool tri_ticket_clean = false;           //                     the stage's ticket word (d_scalars + 3) was cleared by the last frame's re-compaction
+    bool tri_sort_clean = false;             //                     ... and so was d_tri_sort
     uint32_t* d_tmp_final = nullptr;         //                     parts kernel: each command's final indexCount (never written into the command)
     unsigned long long* d_part_status = nullptr;  //                small frames: one granule per (command, part)
     uint32_t tri_epoch = 0;                  //                     tag of the last parts launch on this slot
@@ -118,6 +121,7 @@ struct MipContext {
   uint32_t tri_block_threads = 0;  // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
   uint32_t tri_parts_max = 1024;   // instance counts up to this use the parts kernel (16 work items per command), 0 = off
+  bool tri_recompact_three_launches = false;  // MIP_TUNE_TRI_RECOMPACT_LAUNCHES=3: round 4's count / scan / scatter instead of the one-launch form (A/B, tests)
   uint32_t tri_ticket_slots = 4096; // long triangle streams: slots per range of the range kernel (MIP_TUNE_TRI_RANGE_SLOTS: 256 .. 8192, whole steps of 64)
   uint32_t tri_chunks_from = 0;    // instance counts from this use the range kernel; MIP_TUNE_TRI_CHUNKS_FROM (4294967295 = never: the round-4 kernels)
   bool tri_no_choice = false;      // tuning (MIP_TUNE_TRI_NO_CHOICE): large frames always take the wave-per-command kernel

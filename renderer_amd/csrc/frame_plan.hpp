@@ -73,7 +73,6 @@ struct LaunchPlan {
   TriangleKernel tri = TriangleKernel::none;
   uint32_t tri_threads = 0, tri_blocks = 0;
   uint32_t tri_map_blocks = 0;     // range kernel: grid of the range-map kernel in front of it (one thread per command); the sort kernels' grid too
-  uint32_t tri_wave_blocks = 0;    // TriangleKernel::sorted: grid of the wave-per-command kernel (tri_blocks is the range kernel's)
   bool tri_block_tickets = false;  // the workgroup-per-command kernel pulls its commands from the counter (many more commands than workgroups)
   uint32_t tri_either_blocks = 0;  // > 0: ALSO launch the 256-thread workgroup-per-command kernel over this grid; the two kernels pick
                                    // one of themselves on the device from the frame's own totals (triangle_kernels.hpp, tri_choice)
@@ -213,15 +212,14 @@ inline LaunchPlan plan_frame(const PlanState& st, const PlanRequest& rq) {
     const bool parts = st.tri_parts_max && n <= st.tri_parts_max && !st.tri_block_threads && st.frame_slots == 1 &&
                        st.max_lod_tris <= kPlanTriParts * 256u * kPlanTriPartMaxT;
     if (n >= st.tri_chunks_from && !st.tri_block_threads) {
-      // round 5: equal ranges of the triangle stream, one wave each (triangle_kernels.hpp); frames above tri_block_max instances
-      // ALSO launch the wave-per-command kernel over commands sorted by size class, and one of the two returns at once
+      // round 5: equal ranges of the triangle stream, one wave each (triangle_kernels.hpp); above tri_block_max instances the same grid
+      // takes, per frame and on the device, that decomposition or one wave per command over the size-sorted list (the sort kernels run in front)
       p.tri = n <= st.tri_block_max ? TriangleKernel::chunks : TriangleKernel::sorted;
       p.tri_threads = 256;
       p.need_chunk_scratch = true;
       p.tri_reset_ticket = true;  // long streams: a wave's later ranges are pulled from the counter (and the sorted commands are)
       p.tri_map_blocks = (n + 255u) / 256u;
       p.tri_blocks = st.cu_count * st.tri_chunk_blocks_per_cu;  // resident as a whole: a range's predecessors are running when it looks for them
-      if (p.tri == TriangleKernel::sorted) p.tri_wave_blocks = st.cu_count * 8u;
     } else if (parts) {
       p.tri = TriangleKernel::parts;
       p.tri_threads = 256;

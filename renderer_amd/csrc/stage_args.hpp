@@ -45,7 +45,7 @@ struct TriangleArgs {
   uint32_t* sort_info;            // kSortWords words (layout: triangle_kernels.hpp), zeroed by the host per frame; holds the ticket counter too
   uint32_t first_index_base;      // MipFrame.first_index_base (the length of the triangle stream is taken from the last command)
   uint32_t choice_waves;          // waves of the range kernel's grid: the choice rule's measure of the machine
-  uint32_t choice_mode;           // 0 = run; 1 = run iff the frame is the range kernel's; 2 = run iff it is the wave-per-command kernel's
+  uint32_t choice_mode;           // 0 = run; 1 = run iff the frame is the range decomposition's; 2 = iff the wave-per-command one's; 3 = prepare kernel: either part
   uint32_t pull_tickets;          // workgroup-per-command kernel: pull commands from `ticket` instead of a static stride: 0 = stride, else the
                                   // command count from which a ticket is FOUR consecutive commands (65 536; MIP_TUNE_TRI_BATCH_FROM for tests)
   float pv[16];
@@ -60,6 +60,8 @@ struct RecompactArgs {
   const uint32_t* in_count;
   uint32_t* out_cmds;
   uint32_t* out_count;
+  uint32_t* zero_words;   // n_zero words (<= 1024) cleared at the end: the stage's counters, for the next frame of the slot
+  uint32_t n_zero;
 };
 
 struct RecompactWideArgs {
@@ -68,8 +70,16 @@ struct RecompactWideArgs {
   const uint32_t* in_count;
   uint32_t* out_cmds;
   uint32_t* out_count;
-  uint32_t* block_base;   // one word per 1024 commands: survivors in the block, then their exclusive prefix
+  uint32_t* block_base;   // (round-4 three-launch form) one word per 1024 commands: survivors in the block, then their exclusive prefix
   uint32_t n_blocks;
+  unsigned long long* block_status;  // one-launch form: one granule per 1024 commands {tag : 32 | inclusive : 1 | value : 31}
+  uint32_t epoch;                    // unique per launch on this frame slot, never 0
+  uint32_t* help_counter;            // device word (MipTimings.prefix_helps), or null
+  uint32_t* zero_words;              // as RecompactArgs
+  uint32_t n_zero;
+#ifdef MIP_DEBUG_STAMPS
+  uint32_t debug_skip;               // diagnostic build only: every fourth workgroup never publishes (its successors count its commands themselves)
+#endif
 };
 
 constexpr uint32_t kTriParts = 16;
@@ -103,26 +113,29 @@ struct TriangleChunkArgs {
 #endif
 };
 
-constexpr uint32_t kSortWords = 256;
-// Layout of TriangleArgs.sort_info (kSortWords words, zeroed by the host per frame). Size class k = floor(log2(triangles)).
-constexpr uint32_t kSortHist = 0;      // [32] commands per size class
-constexpr uint32_t kSortCursor = 32;   // [32] by class: where the next command of the class goes in `order`
-constexpr uint32_t kSortStart = 64;    // [32] by RANK d (d = 0: the largest class): first position of the class in `order`
-constexpr uint32_t kSortTickets = 96;  // [32] by rank: tickets up to and including the class
-constexpr uint32_t kSortBatch = 128;   // [32] by rank: commands per ticket
-constexpr uint32_t kSortDone = 160;    // workgroups of the count kernel that have added their histogram
-constexpr uint32_t kSortTicket = 161;  // the ticket counter of the stage
-static_assert(kSortTicket < kSortWords, "sort_info layout");
+// Layout of TriangleArgs.sort_info (kSortWords words; cleared by the re-compaction at the end of every frame, by the host before the
+// first). Size class k = floor(log2(triangles)). Histogram and cursors exist in kSortCopies copies (workgroup b uses copy b % 8): every
+// workgroup adds to them with one atomic per class, and ~800 adds on ONE address are ~9 us (a same-address atomic takes ~11 ns).
+constexpr uint32_t kSortCopies = 8;
+constexpr uint32_t kSortHist = 0;                       // [copies][32] commands per size class
+constexpr uint32_t kSortCursor = kSortCopies * 32;      // [copies][32] by class: commands of the class placed so far by the copy's workgroups
+constexpr uint32_t kSortStart = 2 * kSortCopies * 32;   // [32] by RANK d (d = 0: the largest class): first position of the class in `order`
+constexpr uint32_t kSortTickets = kSortStart + 32;      // [32] by rank: tickets up to and including the class
+constexpr uint32_t kSortBatch = kSortTickets + 32;      // [32] by rank: commands per ticket
+constexpr uint32_t kSortTicket = kSortBatch + 32;       // the ticket counter of the stage
+constexpr uint32_t kSortWords = kSortTicket + 32;
+static_assert(kSortWords <= 1024, "the re-compaction clears the block with one workgroup");
 
 // Launchers (defined in stages_tu.hip). Each enqueues one kernel on `stream`; errors surface through hipGetLastError.
-void launch_triangle_sort(uint32_t blocks, hipStream_t stream, const TriangleArgs& a, uint32_t* order);  // size classes: count + prefix, scatter
+void launch_triangle_stage(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a);  // frames above tri_block_max: range map OR size-class
+                                                                                                                  // histogram, scatter, then ONE grid that takes either decomposition
 uint32_t triangle_chunks_blocks_per_cu();  // workgroups of the range kernel a CU holds at once: its ranges are dealt over a grid that is resident as a whole
 void launch_triangle_cull_chunks(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a);  // range map, then the stage
 void launch_triangle_cull_waves(uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
 void launch_triangle_cull_block(uint32_t threads /* 256 | 512 | 1024 */, uint32_t blocks, hipStream_t stream, const TriangleArgs& a);
 void launch_triangle_cull_parts(uint32_t blocks, hipStream_t stream, const TrianglePartsArgs& a);
 void launch_recompact(hipStream_t stream, const RecompactArgs& a);
-void launch_recompact_wide(hipStream_t stream, const RecompactWideArgs& a);  // count, scan, scatter
+void launch_recompact_wide(hipStream_t stream, const RecompactWideArgs& a);  // one launch (block_status set) or count, scan, scatter
 
 // ---- row f-4: shadow-pass draw lists (light_lists_kernel.hpp) ----
 constexpr uint32_t kMaxLights = 16;  // the shadow atlas is DIM x DIM = 4 x 4 maps, shadow_mapping.rs:24

@@ -39,7 +39,7 @@ uint32_t triangle_chunks_blocks_per_cu() {
   static int per_cu = 0;  // (one device kind per process: gfx950)
   if (per_cu <= 0) {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, mip_triangle_cull_ranges_kernel, 256, 0) != hipSuccess || v < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, mip_triangle_stage_kernel, 256, 0) != hipSuccess || v < 1) {
       (void)hipGetLastError();
       v = 4;
     }
@@ -55,13 +55,18 @@ uint32_t triangle_chunks_blocks_per_cu() {
 }
 
 void launch_triangle_cull_chunks(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a) {
-  hipLaunchKernelGGL(mip_triangle_range_map_kernel, dim3(map_blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(mip_triangle_prepare_kernel, dim3(map_blocks), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(mip_triangle_cull_ranges_kernel, dim3(blocks), dim3(256), 0, stream, a);
 }
 
-void launch_triangle_sort(uint32_t blocks, hipStream_t stream, const TriangleArgs& a, uint32_t* order) {
-  hipLaunchKernelGGL(mip_triangle_sort_count_kernel, dim3(blocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(mip_triangle_sort_scatter_kernel, dim3(blocks), dim3(256), 0, stream, a, order);
+void launch_triangle_stage(uint32_t map_blocks, uint32_t blocks, hipStream_t stream, const TriangleChunkArgs& a) {
+  TriangleChunkArgs p = a;
+  p.t.choice_mode = 3u;  // range map OR size-class histogram, whichever decomposition the frame is for
+  hipLaunchKernelGGL(mip_triangle_prepare_kernel, dim3(map_blocks), dim3(256), 0, stream, p);
+  TriangleArgs w = a.t;
+  w.choice_mode = 2u;    // (returns at once when the frame is the range decomposition's)
+  hipLaunchKernelGGL(mip_triangle_sort_scatter_kernel, dim3(map_blocks), dim3(256), 0, stream, w, const_cast<uint32_t*>(a.t.order));
+  hipLaunchKernelGGL(mip_triangle_stage_kernel, dim3(blocks), dim3(256), 0, stream, a);
 }
 
 void launch_recompact(hipStream_t stream, const RecompactArgs& a) {
@@ -69,6 +74,10 @@ void launch_recompact(hipStream_t stream, const RecompactArgs& a) {
 }
 
 void launch_recompact_wide(hipStream_t stream, const RecompactWideArgs& a) {
+  if (a.block_status) {
+    hipLaunchKernelGGL(mip_recompact_onepass_kernel, dim3(a.n_blocks), dim3(1024), 0, stream, a);
+    return;
+  }
   hipLaunchKernelGGL(mip_recompact_count_kernel, dim3(a.n_blocks), dim3(1024), 0, stream, a);
   hipLaunchKernelGGL(mip_recompact_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
   hipLaunchKernelGGL(mip_recompact_scatter_kernel, dim3(a.n_blocks), dim3(1024), 0, stream, a);

@@ -280,11 +280,9 @@ __device__ __forceinline__ uint32_t tri_size_class(uint32_t index_count) {
   return n_tris ? 31u - (uint32_t)__builtin_clz(n_tris) : 0u;
 }
 
-__global__ __launch_bounds__(256, MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
+// One wave per command (the body of mip_triangle_cull_kernel, and of mip_triangle_stage_kernel when the frame is not the range kernel's).
+__device__ __forceinline__ void triangle_waves_body(const TriangleArgs& a, uint32_t count) {
   const uint32_t lane = threadIdx.x & 63u;
-  if (a.index_total && tri_choice_is_block(a)) return;  // (round 4's pairing) this frame is the workgroup-per-command grid's
-  const uint32_t count = *a.count;
-  if (tri_not_this_grid(a, count)) return;              // (round 5's pairing) this frame is the range kernel's
   float pv[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) pv[k] = a.pv[k];
@@ -356,43 +354,29 @@ __global__ __launch_bounds__(256, MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD) void mip_t
 #endif
 }
 
-// ---- commands by descending size class (round 5) ----
-// count: a histogram of the classes (LDS per workgroup, one global add per class and workgroup); the LAST workgroup to
-// add turns it into positions, tickets and batch sizes, largest class first. scatter: every command to its class's run
-// (the order inside a run is whatever the adds make it: it decides which wave walks which command, nothing else).
-__global__ __launch_bounds__(256) void mip_triangle_sort_count_kernel(const TriangleArgs a) {
-  __shared__ uint32_t s_hist[32];
-  __shared__ uint32_t s_last;
-  const uint32_t tid = threadIdx.x;
+__global__ __launch_bounds__(256, MIP_TRI_WAVE_KERNEL_WAVES_PER_SIMD) void mip_triangle_cull_kernel(const TriangleArgs a) {
+  if (a.index_total && tri_choice_is_block(a)) return;  // (round 4's pairing) this frame is the workgroup-per-command grid's
   const uint32_t count = *a.count;
   if (tri_not_this_grid(a, count)) return;
+  triangle_waves_body(a, count);
+}
+
+// ---- commands by descending size class (round 5) ----
+// count (a part of mip_triangle_prepare_kernel): a histogram of the classes — LDS per workgroup, one global add per class and
+// workgroup into the workgroup's COPY of the histogram. scatter: every workgroup turns the histogram into positions (32 classes:
+// a scan across half a wave, redundantly in every workgroup — no "last workgroup" counter), reserves its commands' places with one
+// add per class on its copy's cursor and writes them; workgroup 0 also leaves positions, tickets and batch sizes for the stage. The
+// order inside a class is whatever the adds make it: it decides which wave walks which command, nothing else.
+__device__ __forceinline__ void triangle_sort_count_part(const TriangleArgs& a, uint32_t count) {
+  __shared__ uint32_t s_hist[32];
+  const uint32_t tid = threadIdx.x;
   if (tid < 32u) s_hist[tid] = 0u;
   __syncthreads();
   const uint32_t c = blockIdx.x * 256u + tid;
   if (c < count) atomicAdd(&s_hist[tri_size_class(a.cmds[c * kCmdWords + 0])], 1u);
   __syncthreads();
-  if (tid < 32u && s_hist[tid]) (void)__hip_atomic_fetch_add(&a.sort_info[kSortHist + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (tid == 0u) {
-    __atomic_thread_fence(__ATOMIC_RELEASE);  // this workgroup's adds are visible before its arrival is
-    s_last = __hip_atomic_fetch_add(&a.sort_info[kSortDone], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-  }
-  __syncthreads();
-  if (s_last == 0u || tid != 0u) return;
-  uint32_t at = 0, tickets = 0;
-  for (uint32_t d = 0; d < 32u; ++d) {
-    const uint32_t k = 31u - d;
-    const uint32_t h = __hip_atomic_load(&a.sort_info[kSortHist + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // a ticket is worth ~4 096 triangles, and at most 16 commands (a small command costs its start-up latency, not its triangles)
-    uint32_t batch = k >= 12u ? 1u : 4096u >> k;
-    if (batch > 16u) batch = 16u;
-    a.sort_info[kSortStart + d] = at;
-    a.sort_info[kSortCursor + k] = at;
-    a.sort_info[kSortBatch + d] = batch;
-    tickets += (h + batch - 1u) / batch;
-    a.sort_info[kSortTickets + d] = tickets;
-    at += h;
-  }
+  if (tid < 32u && s_hist[tid])
+    (void)__hip_atomic_fetch_add(&a.sort_info[kSortHist + (blockIdx.x % kSortCopies) * 32u + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void mip_triangle_sort_scatter_kernel(const TriangleArgs a, uint32_t* order) {
@@ -401,7 +385,34 @@ __global__ __launch_bounds__(256) void mip_triangle_sort_scatter_kernel(const Tr
   const uint32_t tid = threadIdx.x;
   const uint32_t count = *a.count;
   if (tri_not_this_grid(a, count)) return;
-  if (tid < 32u) s_hist[tid] = 0u;
+  const uint32_t copy = blockIdx.x % kSortCopies;
+  if (tid < 64u) {  // wave 0: lane d < 32 takes the class of rank d (d = 0: the largest)
+    const uint32_t k = 31u - (tid & 31u);
+    uint32_t total = 0, below = 0;
+    if (tid < 32u) {
+#pragma unroll
+      for (uint32_t q = 0; q < kSortCopies; ++q) {
+        const uint32_t h = a.sort_info[kSortHist + q * 32u + k];
+        total += h;
+        if (q < copy) below += h;
+      }
+    }
+    // a ticket is worth ~4 096 triangles, and at most 16 commands (a small command costs its start-up latency, not its triangles)
+    uint32_t batch = k >= 12u ? 1u : 4096u >> k;
+    if (batch > 16u) batch = 16u;
+    const uint32_t start = wave_inclusive_scan(total) - total;
+    const uint32_t tickets = tid < 32u ? (total + batch - 1u) / batch : 0u;
+    const uint32_t tickets_upto = wave_inclusive_scan(tickets);
+    if (tid < 32u) {
+      s_hist[k] = 0u;
+      s_base[k] = start + below;  // where this copy's commands of the class begin
+      if (blockIdx.x == 0u) {
+        a.sort_info[kSortStart + tid] = start;
+        a.sort_info[kSortBatch + tid] = batch;
+        a.sort_info[kSortTickets + tid] = tickets_upto;
+      }
+    }
+  }
   __syncthreads();
   const uint32_t c = blockIdx.x * 256u + tid;
   uint32_t k = 0, rank = 0;
@@ -410,7 +421,8 @@ __global__ __launch_bounds__(256) void mip_triangle_sort_scatter_kernel(const Tr
     rank = atomicAdd(&s_hist[k], 1u);
   }
   __syncthreads();
-  if (tid < 32u && s_hist[tid]) s_base[tid] = __hip_atomic_fetch_add(&a.sort_info[kSortCursor + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 32u && s_hist[tid])
+    s_base[tid] += __hip_atomic_fetch_add(&a.sort_info[kSortCursor + copy * 32u + tid], s_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (c < count) order[s_base[k] + rank] = c;
 }
@@ -458,6 +470,104 @@ __global__ __launch_bounds__(1024) void mip_recompact_kernel(const RecompactArgs
   __shared__ uint32_t s_totals[16];
   __shared__ uint32_t s_running;
   recompact_commands<1024>(a.in_cmds, a.index_count, *a.in_count, a.out_cmds, a.out_count, s_totals, s_running);
+  // the stage's counters for the NEXT frame of this slot (the stage itself is over: this kernel runs behind it on the stream)
+  if (threadIdx.x < a.n_zero) a.zero_words[threadIdx.x] = 0u;
+}
+
+// Large frames (more than tri_block_max instances): the same re-compaction in ONE launch of many workgroups (round 4: three —
+// counts per 1 024 commands, one workgroup scanning them, the scatter: 3 x 4.8 us of a 0.37 ms frame). A workgroup counts
+// its 1 024 commands, publishes the count as a tagged granule {tag : 32 | inclusive : 1 | value : 31}, looks back — 64
+// predecessors per round trip, down to the nearest one that has published its INCLUSIVE sum —, publishes its own inclusive
+// sum and scatters. A predecessor that has not published after the patient polls is not waited for: its count is 1 024
+// index counts away, the waiting wave computes it (no wait depends on another workgroup ever running).
+constexpr unsigned long long kRecompactInclusive = 1ull << 31;
+__global__ __launch_bounds__(1024) void mip_recompact_onepass_kernel(const RecompactWideArgs a) {
+  __shared__ uint32_t s_totals[16];
+  __shared__ uint32_t s_exclusive;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t count = *a.in_count;
+  const uint32_t b = blockIdx.x;
+  const uint32_t last_block = count ? (count - 1u) / 1024u : 0u;
+  if (b > last_block) return;
+  const uint32_t k = b * 1024u + tid;
+  const bool valid = k < count;
+  uint32_t w[kCmdWords];
+#pragma unroll
+  for (uint32_t f = 0; f < kCmdWords; ++f) w[f] = valid ? a.in_cmds[(size_t)k * kCmdWords + f] : 0u;
+  if (a.index_count && valid) w[0] = a.index_count[k];
+  const bool keep = valid && w[0] > 0u;
+  const unsigned long long mask = __ballot(keep);
+  if (lane == 0) s_totals[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < 16; ++q) {
+    const uint32_t v = s_totals[q];
+    if (q < wave) before += v;
+    total += v;
+  }
+  if (wave == 0) {
+    const unsigned long long tag = (unsigned long long)a.epoch << 32;
+#ifdef MIP_DEBUG_STAMPS
+    const bool skip_publish = a.debug_skip && (b & 3u) == 1u;  // fault injection: every fourth workgroup publishes nothing; its successors count for it
+#else
+    const bool skip_publish = false;
+#endif
+    if (lane == 0u && b > 0u && !skip_publish) __hip_atomic_store(&a.block_status[b], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t exclusive = 0;
+    for (uint32_t pos = b; pos > 0u;) {
+      const uint32_t lo = pos > 64u ? pos - 64u : 0u;
+      const uint32_t j = lo + lane;
+      const bool need = j < pos;
+      bool ready = !need;
+      unsigned long long g = 0;
+      uint32_t polls = 0;
+      for (;;) {
+        if (!ready) {
+          g = status_load(&a.block_status[j]);
+          ready = (uint32_t)(g >> 32) == a.epoch;
+        }
+        if (__all(ready)) break;
+        if (__builtin_expect(++polls > kPatientPolls, 0)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      unsigned long long missing = __ballot(!ready);
+      while (__builtin_expect(missing != 0ull, 0)) {  // wave-uniform: that block's count, computed here on its owner's behalf
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(missing));
+        const uint32_t jj = lo + q;
+        uint32_t kept = 0;
+        for (uint32_t i = 0; i < 16u; ++i) {
+          const uint32_t kk = jj * 1024u + i * 64u + lane;
+          const bool kv = kk < count && (a.index_count ? a.index_count[kk] : a.in_cmds[(size_t)kk * kCmdWords]) > 0u;
+          kept += (uint32_t)__popcll(__ballot(kv));
+        }
+        if (lane == q) g = tag | kept;
+        if (lane == 0u) {
+          __hip_atomic_store(&a.block_status[jj], tag | kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (an aggregate: the owner's later inclusive store wins)
+          if (a.help_counter) (void)__hip_atomic_fetch_add(a.help_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        missing &= ~(1ull << q);
+      }
+      // from the nearest predecessor that knows its inclusive sum upwards
+      const unsigned long long inclusive = __ballot(need && (g & kRecompactInclusive) != 0ull);
+      const uint32_t from = inclusive ? 63u - (uint32_t)__builtin_clzll(inclusive) : 0u;
+      exclusive += wave_sum(need && lane >= from ? (uint32_t)g & 0x7fffffffu : 0u);
+      if (inclusive) break;
+      pos = lo;
+    }
+    if (lane == 0u) {
+      if (!skip_publish) __hip_atomic_store(&a.block_status[b], tag | kRecompactInclusive | (exclusive + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_exclusive = exclusive;
+      if (b == last_block) *a.out_count = exclusive + total;
+    }
+  }
+  __syncthreads();
+  if (keep) {
+    uint32_t* dst = a.out_cmds + (size_t)(s_exclusive + before + lanes_below(mask)) * kCmdWords;
+#pragma unroll
+    for (uint32_t f = 0; f < kCmdWords; ++f) dst[f] = w[f];
+  }
+  if (b == last_block && tid < a.n_zero) a.zero_words[tid] = 0u;  // the stage's counters for the next frame of this slot
 }
 
 // Large frames: the same re-compaction over many workgroups, as three small launches — per-block
@@ -831,7 +941,7 @@ __global__ __launch_bounds__(256, 4) void mip_triangle_cull_parts_kernel(const T
 // unused slots). Range b = slots [b * S, (b + 1) * S), S = the stream's length over the number of ranges, in whole steps
 // of 64. The part of a command inside a range is a SEGMENT, walked 64 triangles per step with the command's matrix in
 // scalar registers, exactly as the wave-per-command kernel walks a whole command.
-//   * where a range starts: `range_first_cmd`, written by mip_triangle_range_map_kernel (one thread per command);
+//   * where a range starts: `range_first_cmd`, written by mip_triangle_prepare_kernel (one thread per command);
 //   * order: a command's survivors follow those of its earlier triangles. A segment whose command STARTS in the range
 //     knows its position (0) and writes as it goes. The one segment of a range that CONTINUES a command from earlier
 //     ranges — the first — needs that command's survivors there: it is TESTED at once, its 64-bit keep masks kept in LDS
@@ -856,12 +966,20 @@ __host__ __device__ __forceinline__ uint32_t range_slots(uint32_t total, uint32_
   return ticket_slots;
 }
 
-// range b starts with the first command whose slots END behind b * S
-__global__ __launch_bounds__(256) void mip_triangle_range_map_kernel(const TriangleChunkArgs ca) {
+// (range b starts with the first command whose slots END behind b * S)
+// The kernel in front of the stage, one thread per command: for the range decomposition the map of range -> first command; for
+// the wave-per-command decomposition (frames above tri_block_max that are not the range decomposition's: choice_mode 3) the
+// histogram of the size classes and, by the last workgroup to arrive, positions, tickets and batch sizes.
+__global__ __launch_bounds__(256) void mip_triangle_prepare_kernel(const TriangleChunkArgs ca) {
   const TriangleArgs& a = ca.t;
   const uint32_t count = *a.count;
+  if (count == 0u) return;
+  if (a.choice_mode == 3u && !plan_tri_choice_is_ranges(a.max_lod_tris, stream_slots(a, a.first_index_base, count), count, a.choice_waves)) {
+    triangle_sort_count_part(a, count);
+    return;
+  }
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
-  if (c >= count || tri_not_this_grid(a, count)) return;
+  if (c >= count) return;
   const uint32_t base = ca.first_index_base;
   const uint32_t S = range_slots(stream_slots(a, base, count), ca.n_waves, ca.ticket_slots);
   const uint32_t index_count = a.cmds[c * kCmdWords + 0], first_index = a.cmds[c * kCmdWords + 2];
@@ -1001,13 +1119,12 @@ __device__ __forceinline__ uint32_t chunk_lookback(const TriangleChunkArgs& ca, 
   return prefix;
 }
 
-__global__ __launch_bounds__(256, MIP_TRI_CHUNK_WAVES_PER_SIMD) void mip_triangle_cull_ranges_kernel(const TriangleChunkArgs ca) {
+typedef unsigned long long RangeMasks[4][2][kRangeMaskSteps];  // per wave: two buffers of keep masks (LDS of the kernel that runs the body)
+
+__device__ __forceinline__ void triangle_ranges_body(const TriangleChunkArgs& ca, uint32_t count, RangeMasks& s_masks) {
   const TriangleArgs& a = ca.t;
-  __shared__ unsigned long long s_masks[4][2][kRangeMaskSteps];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t count = *a.count;
-  if (count == 0u || tri_not_this_grid(a, count)) return;
   const uint32_t base = ca.first_index_base;
   const uint32_t total = stream_slots(a, base, count);
   const uint32_t S = range_slots(total, ca.n_waves, ca.ticket_slots);
@@ -1093,6 +1210,24 @@ __global__ __launch_bounds__(256, MIP_TRI_CHUNK_WAVES_PER_SIMD) void mip_triangl
     pend = cur;
     buf ^= 1u;
   }
+}
+
+__global__ __launch_bounds__(256, MIP_TRI_CHUNK_WAVES_PER_SIMD) void mip_triangle_cull_ranges_kernel(const TriangleChunkArgs ca) {
+  __shared__ RangeMasks s_masks;
+  const uint32_t count = *ca.t.count;
+  if (count == 0u || tri_not_this_grid(ca.t, count)) return;
+  triangle_ranges_body(ca, count, s_masks);
+}
+
+// Frames above tri_block_max instances: ONE grid, and every workgroup takes the decomposition the frame is for — equal ranges of
+// the triangle stream, or one wave per command over the size-sorted list (plan_tri_choice_is_ranges, from the slot's own command
+// list). (First build of the pairing: two grids of 2 048 workgroups, one of which returned at once — 4.75 us of every frame.)
+__global__ __launch_bounds__(256, MIP_TRI_CHUNK_WAVES_PER_SIMD) void mip_triangle_stage_kernel(const TriangleChunkArgs ca) {
+  __shared__ RangeMasks s_masks;
+  const uint32_t count = *ca.t.count;
+  if (count == 0u) return;
+  if (plan_tri_choice_is_ranges(ca.t.max_lod_tris, stream_slots(ca.t, ca.t.first_index_base, count), count, ca.t.choice_waves)) triangle_ranges_body(ca, count, s_masks);
+  else triangle_waves_body(ca.t, count);
 }
 
 }  // namespace mip

@@ -76,13 +76,11 @@ static void check_one(const PlanState& st, const PlanRequest& rq) {
     CHECK(p.tri_blocks >= 1, "a triangle launch has a grid");
     CHECK(p.need_part_status == (p.tri == TriangleKernel::parts), "granules only for the parts kernel");
     CHECK(p.need_chunk_scratch == (p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted), "range map and granules only for the range kernel");
-    CHECK((p.tri_wave_blocks != 0) == (p.tri == TriangleKernel::sorted), "the second grid only where the device chooses");
     CHECK(p.tri_reset_ticket == (p.tri == TriangleKernel::waves || p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted || p.tri_block_tickets), "the counter is zeroed exactly for the kernels that pull from it");
     CHECK(p.tri_block_tickets == (p.tri == TriangleKernel::block && st.n > 32768u), "the workgroup kernel pulls tickets when commands far outnumber workgroups");
     if (p.tri == TriangleKernel::chunks || p.tri == TriangleKernel::sorted) {
       CHECK(st.n >= st.tri_chunks_from && !st.tri_block_threads, "range kernel preconditions");
       CHECK((p.tri == TriangleKernel::sorted) == (st.n > st.tri_block_max), "sorted commands + device-side choice above tri_block_max");
-      if (p.tri == TriangleKernel::sorted) CHECK(p.tri_wave_blocks == st.cu_count * 8u, "wave grid");
       CHECK(p.tri_blocks == st.cu_count * st.tri_chunk_blocks_per_cu && p.tri_threads == 256, "chunk grid: resident as a whole");
       CHECK((uint64_t)p.tri_map_blocks * 256u >= st.n && (uint64_t)(p.tri_map_blocks - 1u) * 256u < st.n, "chunk map: one thread per possible command");
     } else if (p.tri == TriangleKernel::parts) {

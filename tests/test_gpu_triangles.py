@@ -67,7 +67,7 @@ def test_triangle_cull_matches_oracle(ra, oracle_mod, config, n, allvis):
     assert 0 < survivors < int(r["draw_cmds"]["indexCount"].astype(np.int64).sum())  # something was culled, something survived
 
 
-@pytest.mark.parametrize("mode", ["ranges", "ranges_ticketed", "ranges_or_sorted_waves", "sorted_waves", "ranges_of_a_large_frame",
+@pytest.mark.parametrize("mode", ["ranges", "ranges_ticketed", "ranges_or_sorted_waves", "sorted_waves", "ranges_of_a_large_frame", "recompact_three_launches",
                                   "wave", "wave_only", "tickets", "tickets_x4", "block256", "block512", "block1024", "parts"])
 def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
     """Round 5: the stage is the range kernel (equal ranges of the triangle stream, one per wave, or — long streams — ranges
@@ -80,8 +80,11 @@ def test_every_triangle_kernel_variant(ra, oracle_mod, monkeypatch, mode):
         pass                                                     # the default at this size: one range per wave
     elif mode == "ranges_ticketed":
         monkeypatch.setenv("MIP_TUNE_TRI_RANGE_SLOTS", "256")    # a long stream by this measure: 256-slot ranges, most of them pulled from the counter
+    elif mode == "recompact_three_launches":
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")
+        monkeypatch.setenv("MIP_TUNE_TRI_RECOMPACT_LAUNCHES", "3")  # round 4's count / scan / scatter instead of the one-launch re-compaction
     elif mode in ("ranges_or_sorted_waves", "sorted_waves", "ranges_of_a_large_frame"):
-        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")        # the large-frame path: sort kernels + both grids, one chosen on the device ...
+        monkeypatch.setenv("MIP_TUNE_TRI_BLOCK_MAX", "0")        # the large-frame path: prepare + scatter kernels, one grid, the decomposition chosen on the device ...
         if mode == "sorted_waves":
             monkeypatch.setenv("MIP_TUNE_TRI_CHOICE", "waves")   # ... forced to the wave-per-command grid
         elif mode == "ranges_of_a_large_frame":
@@ -376,8 +379,10 @@ import oracle, renderer_amd
 from test_gpu_triangles import _oracle, _run_gpu
 import torch
 for config, n, knobs in ((3, 3000, {}), (2, 700, {}), (3, 3000, {"MIP_TUNE_TRI_RANGE_SLOTS": "256"}), (2, 700, {"MIP_TUNE_TRI_RANGE_SLOTS": "256"}),
+                         (3, 9000, {"MIP_TUNE_TRI_BLOCK_MAX": "0"}),   # the large-frame path: the one-launch re-compaction over 9 workgroups, every fourth silent under "skip"
+                         (3, 9000, {"MIP_TUNE_TRI_BLOCK_MAX": "0", "MIP_TUNE_TRI_CHOICE": "waves"}),
                          (3, 3000, {"MIP_TUNE_TRI_CHUNKS_FROM": "4294967295"}), (2, 700, {"MIP_TUNE_TRI_CHUNKS_FROM": "4294967295"})):
-    for k in ("MIP_TUNE_TRI_RANGE_SLOTS", "MIP_TUNE_TRI_CHUNKS_FROM"):
+    for k in ("MIP_TUNE_TRI_RANGE_SLOTS", "MIP_TUNE_TRI_CHUNKS_FROM", "MIP_TUNE_TRI_BLOCK_MAX", "MIP_TUNE_TRI_CHOICE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)   # (read when the context is created)
     s = renderer_amd.scene.make_scene(config, n=n)
