@@ -4,7 +4,7 @@
 #  a1  rocprofv3 kernel stats of the default bench command (config 3) and of config 2
 #  a2  FETCH/WRITE PMC passes of the frame kernel at 1 M (config 3) AND at 10 M (config 4: the honest HBM figure), SQ counters at 1 M / 100 k
 #  a3  both frame-kernel orders either side of the crossover (what a launch of mixed orders could gain at 1 M)
-#  b1  PMC summaries of the other kernels whose bench legs read them: per-triangle stage (one-mesh 100 k rows / strips: the size-sorted
+#  b1  PMC summaries of the other kernels whose bench legs read them: per-triangle stage (mip_triangle_stage_kernel; one-mesh 100 k rows / strips: the size-sorted
 #      wave-per-command kernel; mixed 100 k: the range kernel), four views, skinned frame
 #  b2  the N > 1 bench path rehearsed with 2 and 3 ranks on one GPU over gloo (cpu_baseline on the line), the default bench line
 set -o pipefail
@@ -27,9 +27,9 @@ for order in 1 3; do
 done > gpurun_out/r05/orders_around_1m.txt; tail -4 gpurun_out/r05/orders_around_1m.txt
 else
 step "b1 PMC of the other kernels"
-bash tools/pmc_tri.sh r05_tri_rows 2 100000 rows > gpurun_out/r05/pmc_tri_rows.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_rows.log
-bash tools/pmc_tri.sh r05_tri_strips 2 100000 strips > gpurun_out/r05/pmc_tri_strips.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_strips.log
-PMC_TRI_KERNEL="mip_triangle_cull_ranges_kernel(" bash tools/pmc_tri.sh r05_tri_mixed 3 100000 rows > gpurun_out/r05/pmc_tri_mixed.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_mixed.log
+PMC_TRI_KERNEL="mip_triangle_stage_kernel(" bash tools/pmc_tri.sh r05_tri_rows 2 100000 rows > gpurun_out/r05/pmc_tri_rows.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_rows.log
+PMC_TRI_KERNEL="mip_triangle_stage_kernel(" bash tools/pmc_tri.sh r05_tri_strips 2 100000 strips > gpurun_out/r05/pmc_tri_strips.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_strips.log
+PMC_TRI_KERNEL="mip_triangle_stage_kernel(" bash tools/pmc_tri.sh r05_tri_mixed 3 100000 rows > gpurun_out/r05/pmc_tri_mixed.log 2>&1; tail -2 gpurun_out/r05/pmc_tri_mixed.log
 bash tools/pmc_views.sh r05_views 1000000 > gpurun_out/r05/pmc_views.log 2>&1; tail -3 gpurun_out/r05/pmc_views.log
 bash tools/pmc_skin.sh r05_skin > gpurun_out/r05/pmc_skin.log 2>&1; tail -6 gpurun_out/r05/pmc_skin.log
 step "b2 rehearsal, default bench"
