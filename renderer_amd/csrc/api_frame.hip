@@ -333,7 +333,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
           sl.chunk_epoch = 0;
         }
         if (either) {
-          // the commands by descending size class for the wave-per-command grid; one clear covers histogram, arrival counter and ticket
+          // the commands by descending size class for the wave-per-command decomposition; histogram copies, cursors and the ticket live in one block
           if (!sl.d_tri_order) MIP_HIP(ctx, hipMalloc(&sl.d_tri_order, cap * 4));
           if (!sl.d_tri_sort) {
             MIP_HIP(ctx, hipMalloc(&sl.d_tri_sort, mip::kSortWords * 4));
@@ -355,7 +355,6 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
         }
         mip::TriangleChunkArgs ca{};
         ca.t = t;
-        ca.t.choice_mode = either ? 1u : 0u;
         ca.t.final_index_count = sl.d_tmp_final;
         ca.range_first_cmd = sl.d_chunk_first;
         ca.range_status = sl.d_chunk_status;
