@@ -191,8 +191,12 @@ __device__ __forceinline__ void chunk_load_model(const TriangleArgs& a, uint32_t
 typedef unsigned int tri_u32x3 __attribute__((ext_vector_type(3)));
 constexpr uint32_t kTriRegionMax = 0x7ffffff0u;   // bytes a region descriptor spans at most (a command of 178 M triangles)
 constexpr uint32_t kTriDropOffset = 0x80000000u;  // beyond every region: the store is dropped
+// Cache policy of the culled stream's stores (the builtin's last operand: 2 = nt, 16 = sc1): written once, gigabytes per frame, read by
+// nobody in this launch — non-temporal keeps it from pushing the meshes' indices and positions out of the L2 (mixed 1 M instances 2.41 ->
+// 2.24 ms, mixed 100 k 0.369 -> 0.362, one-mesh 100 k unchanged; `sc1 nt`, the frame kernel's policy for its matrices, LOSES here: 3.2 ms —
+// profiles/r05_triangle_store_policy.txt).
 #ifndef MIP_TRI_STORE_AUX
-#define MIP_TRI_STORE_AUX 0
+#define MIP_TRI_STORE_AUX 2
 #endif
 
 // Addresses: the index triples and the positions are read through buffer descriptors too — over the command's own index range and
