@@ -122,13 +122,13 @@ inline LaunchPlan plan_refuse(int32_t status, const char* why) {
 // asks for issue priority while it has walked few of them (triangle_kernels.hpp), so what is left against it is a frame whose largest
 // command is long against a wave's share of the whole frame (share = largest command x waves / triangles of the frame) AND far above
 // the mean command (spread = largest x commands / triangles): then the range kernel, which cuts commands, takes it. Measured
-// (profiles/r05_triangle_stage_modes.txt; ms per frame, range kernel / sorted wave-per-command kernel):
-//   mixed scene (spread ~10): 70 k instances share 4.7: 0.295 / 0.401; 100 k 3.3: 0.395 / 0.454; 200 k 1.6: 0.699 / 0.767;
-//                             400 k 0.8: 1.263 / 1.267; 1 M 0.33: 2.86 / 2.68
-//   one-mesh scene (spread 1.9): 70 k share 0.85: 0.809 / 0.767; 100 k 0.6: 1.106 / 1.003; 300 k 0.2: 2.91 / 2.56
-// Rule: share > 0.7 and spread > 3. Evaluated on the device by both grids (from the slot's own command list); one returns at once.
+// (profiles/r05_triangle_stage_modes.txt, final build; ms per frame, range decomposition / wave-per-command over sorted commands):
+//   mixed scene (spread ~10): 70 k instances share 4.7: 0.278 / 0.359; 100 k 3.3: 0.358 / 0.422; 130 k 2.55: 0.441 / 0.452;
+//                             160 k 2.07: 0.528 / 0.505; 200 k 1.6: 0.653 / 0.591; 400 k 0.8: 1.164 / 1.040; 600 k 0.55: 1.66 / 1.47
+//   one-mesh scene (spread 1.9): 70 k share 0.85: 0.788 / 0.689; 100 k 0.6: 1.052 / 0.925; 300 k 0.2: 2.77 / 2.38
+// Rule: share > 2.25 and spread > 3. Evaluated on the device by every workgroup of the stage's grid (from the slot's own command list).
 constexpr bool plan_tri_choice_is_ranges(uint32_t max_lod_tris, uint32_t total_tris, uint32_t command_count, uint32_t n_waves) {
-  return 10ull * max_lod_tris * n_waves > 7ull * total_tris && (unsigned long long)max_lod_tris * command_count > 3ull * total_tris;
+  return 4ull * max_lod_tris * n_waves > 9ull * total_tris && (unsigned long long)max_lod_tris * command_count > 3ull * total_tris;
 }
 constexpr uint32_t kPlanTriChoiceWaves = 8192;
 constexpr uint32_t kPlanTriBlockTicketsFrom = 32768;  // instances above which the workgroup-per-command kernel pulls tickets
