@@ -834,7 +834,8 @@ def scrambled_dispatch_leg():
     kernels beside a shard kernel). The diagnostic build of the library numbers its tiles by a scrambling permutation of the workgroup
     index (MIP_DEBUG_TILE_ORDER=scramble; never the product), so the tiles that start first miss predecessors that are not even resident
     and compute their aggregates themselves; serialized launches, HIP events, tools/kbench.py as a child process (the library is chosen at
-    import). Rows: 1 M and 2.5 M instances of the mixed scene, scrambled, and 1 M in order from the same build for comparison."""
+    import). Rows: 1 M and 2.5 M instances of the mixed scene, scrambled (as the product behaves, and with the first-mover rule switched
+    off), and 1 M in order from the same build for comparison."""
     import re
     import subprocess
 
@@ -842,11 +843,14 @@ def scrambled_dispatch_leg():
     if not os.path.exists(dbg):
         return {"error": "renderer_amd/lib/libmi_instance_pipeline_dbg.so has not been built (__graft_entry__.build())"}
     rows = {}
-    for label, order in (("scrambled", "scramble"), ("in_order_same_build", None)):
+    for label, order, rule in (("scrambled", "scramble", None), ("scrambled_rule_never", "scramble", "never"), ("in_order_same_build", None, None)):
         env = dict(os.environ)
         env.pop("MIP_DEBUG_TILE_ORDER", None)
+        env.pop("MIP_TUNE_FIRST_MOVER", None)
         if order:
             env["MIP_DEBUG_TILE_ORDER"] = order
+        if rule:
+            env["MIP_TUNE_FIRST_MOVER"] = rule
         sizes = "1000000,2500000" if order else "1000000"
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "--configs", ",".join("3" for _ in sizes.split(",")), "--n", sizes,
                               "--libs", dbg], capture_output=True, text=True, timeout=300, env=env)
@@ -858,7 +862,10 @@ def scrambled_dispatch_leg():
             rows[f"{label}_error"] = (out.stderr or out.stdout)[-400:]
     rows["note"] = ("diagnostic build, tiles numbered by a scrambled permutation of the workgroup index: what a frame costs when the hardware starts "
                     "workgroups in an order the launch did not ask for; round 4: 0.30-0.40 ms at 1 M, 1.0-1.1 ms at 2.5 M (host wall clock, "
-                    "profiles/r04_selfhelp_any_order.txt); round 5 (claims): profiles/r05_selfhelp_claims.txt")
+                    "profiles/r04_selfhelp_any_order.txt); round 5 (claims): profiles/r05_selfhelp_claims.txt. `scrambled`: the product's "
+                    "behaviour — after a launch that had to help, the next launches follow the first-mover rule (tiles mark themselves STARTED, "
+                    "helping waves complete the group accumulators: profiles/r05_first_mover.txt); `scrambled_rule_never`: the rule of rounds 3-4 "
+                    "for every launch (MIP_TUNE_FIRST_MOVER=never)")
     return rows
 
 

@@ -205,7 +205,8 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     ctx->groups_cap = (uint32_t)((tiles_cap + 15) / 16);
     ctx->acc1_offset_words = (uint32_t)((tiles_cap + 31) / 32 * 32);  // keep the accumulators 256-B aligned
     ctx->start1_offset_words = ctx->acc1_offset_words + ctx->groups_cap * 2 * mip::kAccStrideWords;
-    ctx->status_bytes = ((size_t)ctx->start1_offset_words + (size_t)ctx->groups_cap * 2) * 8;
+    ctx->helps_seen_offset_words = ctx->start1_offset_words + ctx->groups_cap * 2;  // one more granule: KernelArgs.helps_seen
+    ctx->status_bytes = ((size_t)ctx->helps_seen_offset_words + 1) * 8;
     for (auto& sl : ctx->slots) {
       MIP_HIP(ctx, hipMalloc(&sl.d_status, ctx->status_bytes));
       MIP_HIP(ctx, hipMemset(sl.d_status, 0, ctx->status_bytes));  // epoch 0 is never used
@@ -215,13 +216,15 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipHostMalloc(&ctx->h_error, 64, hipHostMallocMapped));
     std::memset(ctx->h_error, 0, 64);
     MIP_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_error, ctx->h_error, 0));
-    MIP_HIP(ctx, hipMalloc(&ctx->d_help, 64));
-    MIP_HIP(ctx, hipMemset(ctx->d_help, 0, 64));
+    MIP_HIP(ctx, hipMalloc(&ctx->d_help, kHelpWords * 4));  // [0, kHelpShards): the frame kernel's helps, [kHelpShards]: every other kernel's
+    MIP_HIP(ctx, hipMemset(ctx->d_help, 0, kHelpWords * 4));
 #ifdef MIP_DEBUG_STAMPS
     MIP_HIP(ctx, hipMalloc(&ctx->d_stamps, tiles_cap * 64));
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
+    if (const char* env = std::getenv("MIP_TUNE_FIRST_MOVER"))  // the frame kernel's first-mover rule: always | never | (default) when the previous launch helped
+      ctx->first_mover_env = std::strcmp(env, "always") == 0 ? 1u : (std::strcmp(env, "never") == 0 ? 2u : 0u);
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_THREADS")) {
       const uint32_t v = (uint32_t)std::atoi(env);
       if (v == 256u || v == 512u || v == 1024u) ctx->tri_block_threads = v;
@@ -539,13 +542,25 @@ int32_t mip_set_poses(MipContext* ctx, const void* joint_trs, uint32_t n, int32_
   return MIP_OK;
 }
 
+namespace {
+// Σ of the device's help words (wrapping)
+int32_t read_help_words(MipContext* ctx, uint32_t* out) {
+  uint32_t words[kHelpWords];
+  MIP_HIP(ctx, hipMemcpy(words, ctx->d_help, sizeof words, hipMemcpyDeviceToHost));
+  uint32_t sum = 0;
+  for (uint32_t w : words) sum += w;
+  *out = sum;
+  return MIP_OK;
+}
+}  // namespace
+
 const char* mip_last_error(const MipContext* ctx) { return ctx ? ctx->err : "null context"; }
 
 int32_t mip_get_timings(MipContext* ctx, MipTimings* out) {
   if (!ctx || !out) return MIP_ERR_INVALID_ARGUMENT;
   if (int32_t rc = bind_device(ctx)) return rc;
-  uint32_t helps = 0;  // the device adds (kernels that are in flight may still be adding), the host only reads: a blocking 4-byte copy
-  MIP_HIP(ctx, hipMemcpy(&helps, ctx->d_help, 4, hipMemcpyDeviceToHost));
+  uint32_t helps = 0;  // the device adds (kernels that are in flight may still be adding), the host only reads: a small blocking copy
+  if (int32_t rc = read_help_words(ctx, &helps)) return rc;
   ctx->timings.prefix_helps = helps - ctx->help_base;  // (wrapping difference: cumulative since create or mip_reset_timings)
   *out = ctx->timings;
   return MIP_OK;
@@ -557,7 +572,7 @@ int32_t mip_reset_timings(MipContext* ctx) {
   // the help counter is written by kernels that may be in flight: the device word is never cleared, the host keeps the value it
   // had at the reset (round 4 cleared it only when nothing was in flight, and reported the old count beside freshly reset fields otherwise)
   uint32_t helps = 0;
-  MIP_HIP(ctx, hipMemcpy(&helps, ctx->d_help, 4, hipMemcpyDeviceToHost));
+  if (int32_t rc = read_help_words(ctx, &helps)) return rc;
   ctx->help_base = helps;
   ctx->timings = MipTimings{};
   return MIP_OK;

@@ -19,16 +19,18 @@ int32_t ensure_staging(MipContext* ctx, const MipOutputs* out) {
 
 using FrameKernel = mip::FrameKernelFn;
 template <bool kBox, bool kGeneral, int kWire>
-FrameKernel pick_order(int order) {
-  if (order != 1) return mip::frame_kernel_commands_first(kBox, kGeneral, kWire);
+FrameKernel pick_order(int order, bool first_mover) {
+  if (order != 1) return mip::frame_kernel_commands_first(kBox, kGeneral, kWire, first_mover);
+  if constexpr (mip::KernelArgs::kFirstMoverAdds)
+    if (first_mover) return (FrameKernel)mip::mip_instance_pipeline_kernel<kBox, kGeneral, 1, kWire, true>;
   return (FrameKernel)mip::mip_instance_pipeline_kernel<kBox, kGeneral, 1, kWire>;
 }
-// The instantiation a plan names.
-FrameKernel frame_kernel_of(const mip::LaunchPlan& p) {
-  if (p.box_override) return pick_order<true, true, 0>(p.order);  // (plan_frame refuses MIP_OUT_WIRE for skinned frames)
-  if (p.wire == 2) return p.general ? pick_order<false, true, 2>(p.order) : pick_order<false, false, 2>(p.order);
-  if (p.wire == 1) return p.general ? pick_order<false, true, 1>(p.order) : pick_order<false, false, 1>(p.order);
-  return p.general ? pick_order<false, true, 0>(p.order) : pick_order<false, false, 0>(p.order);
+// The instantiation a plan names; `first_mover`: the one that follows the first-mover rule (KernelArgs.first_mover_rule == 1).
+FrameKernel frame_kernel_of(const mip::LaunchPlan& p, bool first_mover) {
+  if (p.box_override) return pick_order<true, true, 0>(p.order, first_mover);  // (plan_frame refuses MIP_OUT_WIRE for skinned frames)
+  if (p.wire == 2) return p.general ? pick_order<false, true, 2>(p.order, first_mover) : pick_order<false, false, 2>(p.order, first_mover);
+  if (p.wire == 1) return p.general ? pick_order<false, true, 1>(p.order, first_mover) : pick_order<false, false, 1>(p.order, first_mover);
+  return p.general ? pick_order<false, true, 0>(p.order, first_mover) : pick_order<false, false, 0>(p.order, first_mover);
 }
 
 mip::PlanState plan_state(const MipContext* ctx) {
@@ -71,6 +73,20 @@ mip::PlanRequest plan_request(const MipOutputs* out, bool skinned) {
   return rq;
 }
 
+// Whether the launch that is being prepared follows the frame kernel's first-mover rule: for kFirstMoverLaunches launches after
+// tile 0 of some launch found that waves had to help (the device writes the help count to a pinned word; reading it costs nothing).
+uint32_t first_mover_rule_now(MipContext* ctx) {
+  if (ctx->first_mover_env) return ctx->first_mover_env == 1u ? 1u : 0u;
+  const uint32_t hint = ((volatile uint32_t*)ctx->h_error)[kHelpHintWord];
+  if (hint != ctx->help_hint_seen) {
+    ctx->help_hint_seen = hint;
+    ctx->first_mover_launches_left = kFirstMoverLaunches;
+  }
+  if (ctx->first_mover_launches_left == 0) return 0u;
+  ctx->first_mover_launches_left -= 1;
+  return 1u;
+}
+
 // Everything of a launch except the tag: resident inputs, output pointers, prefix state, frame.
 void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame* frame, const MipOutputs* out,
                       bool device_out, mip::KernelArgs& a) {
@@ -93,6 +109,9 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.groups_cap = ctx->groups_cap;
   a.error_flag = ctx->d_error;
   a.help_counter = ctx->d_help;
+  a.helps_seen = reinterpret_cast<uint32_t*>(sl.d_status + ctx->helps_seen_offset_words);
+  a.help_hint = ctx->first_mover_env ? nullptr : ctx->d_error + kHelpHintWord;
+  a.first_mover_rule = ctx->first_mover_env == 1u ? 1u : 0u;  // (recorded launches keep this; a direct launch asks first_mover_rule_now)
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
@@ -220,6 +239,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
   mip::KernelArgs a{};
   fill_kernel_args(ctx, sl, frame, out, device_out, a);
   a.group_shift = plan.group_shift;
+  if (plan.uses_prefix_state) a.first_mover_rule = first_mover_rule_now(ctx);
   if (plan.need_tri_scratch) {
     // the instance kernel emits into the slot's scratch list; the triangle stage rewrites
     // indexCount there and the final compaction lands in the caller's buffers
@@ -277,7 +297,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
     {
       void* params[1] = {&a};
       if (plan.general) ctx->timings.general_launches += 1;
-      MIP_HIP(ctx, hipLaunchKernel((const void*)frame_kernel_of(plan), dim3(plan.n_tiles), dim3(mip::kTile), params, ctx->lds_pad, stream));
+      MIP_HIP(ctx, hipLaunchKernel((const void*)frame_kernel_of(plan, a.first_mover_rule == 1u), dim3(plan.n_tiles), dim3(mip::kTile), params, ctx->lds_pad, stream));
     }
     if (plan.tri != mip::TriangleKernel::none) {
       mip::TriangleArgs t{};
@@ -292,7 +312,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       t.capacity = out->culled_index_capacity;
       t.first_instance_base = frame->first_instance_base;
       t.error_flag = ctx->d_error;
-      t.help_counter = ctx->d_help;
+      t.help_counter = ctx->d_help + mip::kHelpShards;
       t.ticket = sl.d_scalars + 3;
       t.geometry_finite = ctx->geometry_finite ? 1u : 0u;
       std::memcpy(t.pv, frame->pv, sizeof t.pv);
@@ -440,7 +460,7 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
           }
           r.block_status = sl.d_tmp_blocks;
           r.epoch = ++sl.recompact_epoch;
-          r.help_counter = ctx->d_help;
+          r.help_counter = ctx->d_help + mip::kHelpShards;
           r.zero_words = zero_words;
           r.n_zero = n_zero;
 #ifdef MIP_DEBUG_STAMPS
@@ -595,7 +615,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           hipKernelNodeParams kp{};
           const mip::LaunchPlan plan = mip::plan_frame(plan_state(ctx), plan_request(out, false));  // validated by mip_run_many
           a.group_shift = plan.group_shift;
-          kp.func = (void*)frame_kernel_of(plan);
+          kp.func = (void*)frame_kernel_of(plan, a.first_mover_rule == 1u);
           kp.gridDim = dim3(plan.n_tiles);
           kp.blockDim = dim3(mip::kTile);
           kp.sharedMemBytes = ctx->lds_pad;
@@ -761,7 +781,7 @@ static int32_t run_views_chunk(MipContext* ctx, const MipFrame* frames, const Mi
       w.group_shift = a.n_tiles <= 512 ? 4u : (a.n_tiles <= 2048 ? 5u : 6u);
       w.epoch = e;
       w.error_flag = ctx->d_error;
-      w.help_counter = ctx->d_help;
+      w.help_counter = ctx->d_help + mip::kHelpShards;
       w.bitmap = outs[v].visible_bitmap;
       w.cmds = (uint32_t*)outs[v].draw_cmds;
       w.draw_count = outs[v].draw_count;

@@ -23,6 +23,11 @@
 #include <string>
 #include <vector>
 
+constexpr uint32_t kHelpWords = mip::kHelpShards + 1;  // MipContext::d_help
+constexpr uint32_t kHelpHintWord = 8;                  // of MipContext::h_error (the error words are [0, mip::kErrWords))
+constexpr uint32_t kFirstMoverLaunches = 8;            // launches that follow the first-mover rule after a hint
+static_assert(kHelpHintWord >= mip::kErrWords, "the hint must not be an error word");
+
 struct MipContext {
   int device = -1;
   uint32_t max_instances = 0, max_meshes = 0, cfg_flags = 0;
@@ -116,7 +121,12 @@ struct MipContext {
   int cu_count = 0;
   // layout of a slot's prefix state (words of 8 bytes)
   size_t status_bytes = 0;
-  uint32_t acc1_offset_words = 0, start1_offset_words = 0, groups_cap = 0;
+  uint32_t acc1_offset_words = 0, start1_offset_words = 0, helps_seen_offset_words = 0, groups_cap = 0;
+  // the frame kernel's first-mover rule (instance_kernel.hpp, KernelArgs.first_mover_rule): followed by the launches that come
+  // after a launch whose tile 0 saw new helps (it writes the count to h_error[kHelpHintWord])
+  uint32_t first_mover_env = 0;           // MIP_TUNE_FIRST_MOVER=always|never -> 1|2, read at context creation; 0: as the hints say
+  uint32_t help_hint_seen = 0;            // the hint word's value when the host last looked
+  uint32_t first_mover_launches_left = 0; // launches that still follow the rule
   uint32_t lds_pad = 0;  // tuning only (MIP_TUNE_LDS_PAD): dynamic LDS bytes that cap workgroups per CU
   uint32_t tri_block_threads = 0;  // tuning (MIP_TUNE_TRI_BLOCK_THREADS): 256 / 512 / 1024, 0 = by instance count
   uint32_t tri_block_max = 65536;  // instance counts up to this use the workgroup-per-command triangle kernel
@@ -136,7 +146,7 @@ struct MipContext {
   float box_abs = 0.f;  // largest sum of |box coordinates| over the mesh table (the census' overflow bound)
   uint32_t* d_census = nullptr;
   uint32_t* h_error = nullptr;  // pinned, device-visible: error words [0, kErrWords)
-  uint32_t* d_help = nullptr;   // device memory: helped tile aggregates (MipTimings.prefix_helps); read back by mip_get_timings
+  uint32_t* d_help = nullptr;   // device memory, kHelpWords words: helped tile aggregates (MipTimings.prefix_helps = their sum); read back by mip_get_timings
   uint32_t help_base = 0;       // its value at the last mip_reset_timings
   uint32_t* d_error = nullptr;  // device alias of h_error
   uint32_t carried_error_bits = 0;  // error bits a synchronous call saw while asynchronous work was in flight: reported then AND by the next mip_wait

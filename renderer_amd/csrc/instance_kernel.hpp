@@ -73,43 +73,60 @@ struct alignas(16) MeshDraw {
 };
 
 struct KernelArgs {
+  // The first-mover rule (mark_tile_started): a tile's workgroup marks its granule STARTED when it starts, and whoever moves a
+  // granule from an earlier launch's value to this launch's — the owner, or a wave that computes the tile for it — adds the tile
+  // to its group's accumulator, so that groups complete without their owners. The mark is a returning device-scope atomic at the
+  // head of every tile: +0.3 us per launch whether anybody helps or not (profiles/r05_first_mover_ab.txt), so a launch follows
+  // the rule only when recent launches had to help (`first_mover_rule`: note_helps_for_the_host), or when told to.
+#ifndef MIP_FIRST_MOVER_ADDS  // 0: A/B builds only (tools/r05_first_mover.sh) — the rule of rounds 3-4 whatever happens
+#define MIP_FIRST_MOVER_ADDS 1
+#endif
+  static constexpr bool kFirstMoverAdds = MIP_FIRST_MOVER_ADDS != 0;
+  // ---- what every wave of every tile reads before its first instruction that depends on memory: 184 bytes = three 64-byte lines
+  //      of the argument block (with the fields in the order they were added, these were spread over five lines; one line more in
+  //      front of the planes cost a 100 k launch 0.15 us: profiles/r05_first_mover_ab.txt) ----
   const float* pos;             // n*3
   const float4* rot;            // n  [i,j,k,w]
   const float* scale;           // n
   const uint32_t* mesh_id;      // n
   const MeshEntry* meshes;      // m
-  const MeshDraw* mesh_draw;    // m
+  const MeshDraw* mesh_draw;    // m (the commands-first order gathers from it at the tile's head)
+  uint32_t* cmds;               // n*5 or null
+  // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
+  // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
+  // without re-recording: the host refreshes the ring with one copy per replay
+  const uint32_t* frame_ring;   // this launch's FrameWords, or null
+  uint32_t n;
+  uint32_t first_instance_base;
+  uint32_t first_index_base;
+  float planes[24];
+  float cam[3];
+  // ---- the tile's aggregate and its stores ----
+  uint32_t n_tiles;
+  uint32_t epoch;               // 1 .. 2^31-1, unique per launch
+  uint32_t group_shift;         // log2(tiles per group), <= 6
+  uint32_t groups_cap;
+  unsigned long long* status0;  // level 0: one tagged granule per tile
+  unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
+  unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
   float4* model;                // n*4 or null
   uint32_t* bitmap;             // ceil(n/32) or null
-  uint32_t* cmds;               // n*5 or null
+  uint32_t bitmap_words;
+  uint32_t n_meshes;            // mesh-table entries
   uint32_t* draw_count;         // with cmds
   uint32_t* index_total;        // optional
+  // ---- optional outputs, the cold path ----
   uint32_t* src_index_offset;   // optional: per emitted command, where its LOD's indices start (row f-1)
   float* world_aabb;            // n*6 or null
   uint4* tlas_instances;        // n x VkAccelerationStructureInstanceKHR (64 B) or null (row f-4)
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
   const float* box_override;    // n*8 or null: per-instance mesh-space box {min xyz, -, max xyz, -} that replaces the mesh table's (skinned instances)
-  unsigned long long* status0;  // level 0: one tagged granule per tile
-  unsigned long long* acc1;     // level 1: [2 parities][groups_cap] 64-bit accumulators
-  unsigned long long* start1;   // level 1: exclusive prefix at the start of each group, 2 tagged granules
-  uint32_t groups_cap;
-  uint32_t group_shift;         // log2(tiles per group), <= 6
-  uint32_t* error_flag;         // host-mapped error words
-  uint32_t* help_counter;       // DEVICE memory: tile aggregates that waiting tiles computed themselves (MipTimings.prefix_helps)
-  uint32_t n;
-  uint32_t n_tiles;
-  uint32_t epoch;               // 1 .. 2^31-1, unique per launch
-  uint32_t bitmap_words;
-  uint32_t n_meshes;            // mesh-table entries
   uint32_t wire_index_bits;     // MIP_OUT_WIRE_PACKED: bits of a record that hold the instance index (mesh id above them, LOD in bit 31)
-  // the frame: in the argument block for a direct launch; `frame_ring` (device memory, 128-B entries)
-  // instead when the launch is a node of a recorded graph, so that a replay can carry a new camera
-  // without re-recording: the host refreshes the ring with one copy per replay
-  uint32_t first_instance_base;
-  uint32_t first_index_base;
-  float planes[24];
-  float cam[3];
-  const uint32_t* frame_ring;   // this launch's FrameWords, or null
+  uint32_t first_mover_rule;    // 1: this launch follows the first-mover rule (the host's choice: api_frame.hip, MIP_TUNE_FIRST_MOVER)
+  uint32_t* error_flag;         // host-mapped error words
+  uint32_t* help_counter;       // DEVICE memory: tile aggregates that waiting tiles computed themselves (MipTimings.prefix_helps), kHelpShards words
+  uint32_t* helps_seen;         // DEVICE memory, one word beside the prefix state: the help count the last launch that looked saw
+  uint32_t* help_hint;          // host-mapped word (or null: nobody is told): note_helps_for_the_host
 #ifdef MIP_EXP_FAKE_DELAY
   uint32_t delay_first, delay_last;  // tuning builds: tiles in [first, last) idle in place of the look-up
 #endif
@@ -441,14 +458,21 @@ __device__ __forceinline__ unsigned long long status_load(const unsigned long lo
 // Called by ONE lane of the tile once its aggregate is known. `A` is anything that carries a prefix
 // state: status0, acc1, start1, groups_cap, group_shift, epoch, error_flag (KernelArgs, or one view
 // of the multi-view kernel).
+// `adds_to_group`: false when a helping wave has added (or is going to add) this tile to the accumulator on the owner's behalf
+// (A::kFirstMoverAdds; mark_tile_started tells the owner).
 template <class A>
-__device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uint32_t count, uint32_t sum) {
+__device__ __forceinline__ void add_to_group(const A& a, uint32_t tile, uint32_t count, uint32_t sum) {
+  const uint32_t group = tile >> a.group_shift;
+  const unsigned long long add = ((unsigned long long)sum << 32) | (1ull << kAccCountBits) | count;
+  (void)__hip_atomic_fetch_add(&a.acc1[((size_t)(a.epoch & 1u) * a.groups_cap + group) * kAccStrideWords], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class A>
+__device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uint32_t count, uint32_t sum, bool adds_to_group = true) {
   const unsigned long long granule = ((unsigned long long)sum << 32) | ((unsigned long long)a.epoch << kTileCountBits) | count;
   __hip_atomic_store(&a.status0[tile], granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t group = tile >> a.group_shift;
   const uint32_t parity = a.epoch & 1u;
-  const unsigned long long add = ((unsigned long long)sum << 32) | (1ull << kAccCountBits) | count;
-  (void)__hip_atomic_fetch_add(&a.acc1[((size_t)parity * a.groups_cap + group) * kAccStrideWords], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (adds_to_group) add_to_group(a, tile, count, sum);
   if ((tile & ((1u << a.group_shift) - 1u)) == 0u)  // first tile of the group: reset the next launch's word
     __hip_atomic_store(&a.acc1[((size_t)(parity ^ 1u) * a.groups_cap + group) * kAccStrideWords], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -459,13 +483,15 @@ __device__ __forceinline__ void publish_aggregate(const A& a, uint32_t tile, uin
 // because another tenant of the GPU holds the compute units it would run on, because a debugger holds it — is then not
 // waited for: the waiting wave computes that tile's aggregate ITSELF from the tile's inputs (`help`, supplied by the
 // kernel: the same loads and the same arithmetic the owner runs, so the same {count, sum}) and publishes the level-0
-// granule on the owner's behalf (idempotent: the owner stores the same 8 bytes later; only owners add to the level-1
-// accumulators, so those stay exact). This is decoupled look-back with a fallback: the launch makes progress in ANY
+// granule on the owner's behalf (idempotent: the owner stores the same 8 bytes later; a tile is added to its level-1
+// accumulator exactly once — by its owner, or, in the frame kernel since round 5, by whoever was first to replace the granule
+// of an earlier launch: mark_tile_started — so those stay exact). This is decoupled look-back with a fallback: the launch makes progress in ANY
 // order the hardware starts workgroups in, with no ticket at the head of every workgroup (11 ns each, serialised) and
 // no second launch. In-order dispatch — what an idle chip does — is now a performance property (no helps), not a
 // correctness assumption. Helps are counted in a device word (MipTimings.prefix_helps).
 // Round 3 and before: the same polls bounded at 0.5 s, then MIP_ERR_TIMEOUT, a ticketed re-issue and a recovery path.
 constexpr uint32_t kPatientPolls = 64;
+constexpr uint32_t kNotStartedPolls = 2;   // when a tile of the own group has not started (kernels whose tiles mark themselves STARTED)
 constexpr uint32_t kImpatientPolls = 12;  // when more than eight of the words a tile needs are missing (resolve_prefix)
 constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators a tile sums itself
 
@@ -473,14 +499,71 @@ constexpr uint32_t kLevel1Window = 64;  // most recent groups whose accumulators
 // tile's aggregate on the owner's behalf at this moment (count field all ones, which no tile can count): the other waiting waves
 // then compute other tiles, or look again in a moment, instead of computing the same tile by the dozen.
 constexpr uint32_t kClaimedCount = (1u << kTileCountBits) - 1u;
-static_assert(kTile < kClaimedCount, "the claim marker must not be a count");
+// ... or STARTED: the owner's workgroup is running (its first instruction swaps this in, kernels with A::kFirstMoverAdds) and has
+// not published yet. A tile whose granule still carries an EARLIER launch's tag after the looking tile has done all of its own
+// arithmetic is a tile whose workgroup the hardware has not started: waiting for it buys nothing, it is computed at once; a
+// STARTED one publishes within microseconds and is waited for like a claimed one.
+constexpr uint32_t kStartedCount = kClaimedCount - 1u;
+static_assert(kTile < kStartedCount, "the markers must not be counts");
 template <class A>
 __device__ __forceinline__ bool granule_of_this_launch(const A& a, unsigned long long g) {
   return (((uint32_t)g >> kTileCountBits) & kMaxEpoch) == a.epoch;
 }
 template <class A>
 __device__ __forceinline__ bool granule_ready(const A& a, unsigned long long g) {
-  return granule_of_this_launch(a, g) && ((uint32_t)g & kClaimedCount) != kClaimedCount;
+  return granule_of_this_launch(a, g) && ((uint32_t)g & kClaimedCount) < kStartedCount;
+}
+// First instruction of a tile's workgroup (one lane). Returns whether a helping wave got to the tile first — it then adds the tile
+// to the group's accumulator, and the owner must not (publish_aggregate's adds_to_group). The swap overwrites what the helper
+// published with STARTED: the owner publishes the same 8 bytes again in a few microseconds.
+// Tile 0's resolving wave (it has no prefix to resolve): has anybody helped since the last launch of this prefix state that looked?
+// Then it tells the HOST (one system-scope store to a pinned word, `help_hint`), which makes its next few launches follow the
+// first-mover rule (KernelArgs.first_mover_rule, api_frame.hip). One wave per launch asks, off every other tile's path, and the
+// rule reaches the kernel as an argument. Measured and not kept: the helping waves saying so themselves (thousands of stores to
+// one word are served one at a time, ~8 ns each: 2.5 M instances in scrambled order, 20 000 helps, 0.19 -> 0.36 ms), and every
+// tile reading a device word for the rule (+0.2 us per launch at 100 k as a vector load behind the instance loads, +0.7 us as a
+// scalar load, which the compiler waits for before it issues them). A degraded environment lasts many frames: the rule sets in
+// a launch or two after the first help and ends a few launches after the last.
+constexpr uint32_t kHelpShards = 16;  // words of help_counter the frame kernel's helpers spread their counts over
+template <class A>
+__device__ __forceinline__ void note_helps_for_the_host(const A& a, uint32_t lane) {
+  if constexpr (A::kFirstMoverAdds) {
+    if (!a.help_hint) return;
+    uint32_t h = lane < kHelpShards ? __hip_atomic_load(&a.help_counter[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t seen = __hip_atomic_load(a.helps_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h = wave_sum(h);
+    if (lane == 0u && h != seen) {
+      __hip_atomic_store(a.helps_seen, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.help_hint, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// Two halves, because the compiler waits for a returning atomic where it is issued when the issue sits in a branch of its own —
+// here before the wave has issued its instance loads, a round trip at the head of every tile (+0.4-0.7 us per launch measured):
+// the swap is issued as it stands, under the lanes of `who`, and its answer is waited for where it is needed, long after
+// (loads and returning atomics come back in order, so every wait the compiler places for a later load covers it too).
+template <class A>
+__device__ __forceinline__ unsigned long long mark_tile_started_issue(const A& a, uint32_t tile, bool who) {
+  unsigned long long g = ((unsigned long long)a.epoch << kTileCountBits) | kStartedCount;  // in: the STARTED granule, out: what was there
+  const unsigned long long* p = &a.status0[tile];
+  const unsigned long long lanes = __ballot(who);
+  const uint32_t zero = 0;
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %[saved], exec\n\t"
+      "s_mov_b64 exec, %[lanes]\n\t"
+      "global_atomic_swap_x2 %[g], %[zero], %[g], %[p] sc0\n\t"
+      "s_mov_b64 exec, %[saved]"
+      : [g] "+v"(g), [saved] "=&s"(saved)
+      : [lanes] "s"(lanes), [zero] "v"(zero), [p] "s"(p)
+      : "memory");
+  return g;
+}
+// whether a helping wave got to the tile first (meaningful in the lanes of `who` only)
+template <class A>
+__device__ __forceinline__ bool mark_tile_started_answer(const A& a, unsigned long long g) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g));
+  return granule_of_this_launch(a, g);
 }
 constexpr uint32_t kClaimPolls = 48;  // looks at a claimed tile before the claim is overridden (a help takes one or two of them)
 
@@ -489,7 +572,7 @@ constexpr uint32_t kClaimPolls = 48;  // looks at a claimed tile before the clai
 // help different tiles first (each publishes what it computed; the others then find it).
 template <class A, class Help>
 __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, uint32_t count, uint32_t lane, uint32_t spread,
-                                                  Help& help, uint32_t& c, uint32_t& s) {
+                                                  Help& help, uint32_t& c, uint32_t& s, bool first_mover_rule, uint32_t self) {
   // (c and s are wave-uniform, and so is the set of tiles still to be summed; nothing per lane stays alive across a help: the
   //  cold path must fit the hot path's registers)
   unsigned long long pending = count >= 64u ? ~0ull : ((1ull << count) - 1ull);
@@ -517,6 +600,9 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
     unsigned long long open = pending & ~__ballot(claimed);
     if (!open) {
       if (++idle_looks <= kClaimPolls) {
+#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_HELP_STAMPS)  // experiment (tools/r05_help_stamps.py): looks at tiles somebody else is computing
+        if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += 1ull;
+#endif
         __builtin_amdgcn_s_sleep(4);
         continue;
       }
@@ -531,21 +617,33 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
     bool took = true;
     if (lane == 0u) {
       unsigned long long expected = seen;
-      const unsigned long long claim = ((unsigned long long)a.epoch << kTileCountBits) | kClaimedCount;
-      took = seen == claim ||  // (an overridden claim: nothing to swap)
-             __hip_atomic_compare_exchange_strong(&a.status0[u], &expected, claim, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the claim names its claimant — `self`, the waiting wave's own tile — so that an expired claim is taken over by
+      //  ONE of the waves that gave up on it, with this same swap, and not computed by all of them at once: scrambled order,
+      //  2.5 M instances: 20 400 helps for 7 700 missing tiles before)
+      const unsigned long long claim = ((unsigned long long)(self + 1u) << 32) | ((unsigned long long)a.epoch << kTileCountBits) | kClaimedCount;
+      took = __hip_atomic_compare_exchange_strong(&a.status0[u], &expected, claim, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     took = __builtin_amdgcn_readfirstlane((int)took) != 0;
     if (!took) continue;  // published or claimed since the look: the next pass sees which
+    // the ONE agent that replaces an earlier launch's granule — this wave's swap just did, or the owner's first instruction would
+    // have — adds the tile to its group (an overridden claim or a STARTED tile is somebody else's to add)
+    const bool first_mover = first_mover_rule && !granule_of_this_launch(a, seen);
     idle_looks = 0;
+#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_HELP_STAMPS)
+    const unsigned long long help_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned long long agg = help(u);  // {sum : 32 | count : 32}, wave-uniform
     const uint32_t uc = (uint32_t)agg, us = (uint32_t)(agg >> 32);
+#if defined(MIP_DEBUG_STAMPS) && defined(MIP_EXP_HELP_STAMPS)  // ticks inside help() in the low half, helps in the high half
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += (__builtin_amdgcn_s_memrealtime() - help_t0) | (1ull << 32);
+#endif
     if (lane == 0u) {
       __hip_atomic_store(&a.status0[u], ((unsigned long long)us << 32) | ((unsigned long long)a.epoch << kTileCountBits) | uc,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (a DEVICE word: as a system-scope atomic on the host-mapped error block every help cost ~1 us of PCIe round trip, serialised
       //  on one address — 10 000 helps per frame were 10 ms, and that, not the helping, was the degraded mode's cost)
-      (void)__hip_atomic_fetch_add(a.help_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add(a.help_counter + (A::kFirstMoverAdds ? u % kHelpShards : 0u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (first_mover) add_to_group(a, u, uc, us);
     }
     c += uc;
     s += us;
@@ -556,13 +654,13 @@ __device__ __forceinline__ void sum_tiles_helping(const A& a, uint32_t first, ui
 // The prefix of `tile` without waiting for anybody (cold path of resolve_prefix).
 template <class A, class Help>
 __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile, uint32_t lane, Help& help,
-                                                                 uint32_t& base_count, uint32_t& base_sum) {
+                                                                 uint32_t& base_count, uint32_t& base_sum, bool first_mover_rule) {
   const uint32_t group = tile >> a.group_shift;
   const uint32_t group_first = group << a.group_shift;
   const uint32_t per_group = 1u << a.group_shift;
   const unsigned long long* acc = &a.acc1[(size_t)(a.epoch & 1u) * a.groups_cap * kAccStrideWords];
   uint32_t c = 0, s = 0;
-  sum_tiles_helping(a, group_first, tile - group_first, lane, tile, help, c, s);  // earlier tiles of the own group
+  sum_tiles_helping(a, group_first, tile - group_first, lane, tile, help, c, s, first_mover_rule, tile);  // earlier tiles of the own group
   // earlier groups: from the published start of group g_lo if there is one, else all of them
   uint32_t lo = group > kLevel1Window ? group - kLevel1Window : 0u;
   if (lo > 0u) {
@@ -599,12 +697,29 @@ __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile
     // of the waves started at group 0 and walked upwards together — a chain of 30 visits instead of one round of helps)
     const uint32_t span = group - gb < 64u ? group - gb : 64u;
     const uint32_t rot = ((tile * 2654435761u) >> 12) % span;
+    bool walked = false;
 #pragma nounroll
     while (open) {
+      if (first_mover_rule && walked) {
+        // helping waves complete groups on their owners' behalf: what has become complete while this wave walked the last group is
+        // taken from its accumulator (one look for all of them) instead of tile by tile
+        uint32_t myc = 0, mys = 0;
+        bool complete = false;
+        if ((open >> lane) & 1ull) {
+          const unsigned long long w = status_load(&acc[(size_t)gg * kAccStrideWords]);
+          complete = ((uint32_t)w >> kAccCountBits) == per_group;
+          if (complete) { myc = (uint32_t)w & ((1u << kAccCountBits) - 1u); mys = (uint32_t)(w >> 32); }
+        }
+        c += wave_sum(myc);
+        s += wave_sum(mys);
+        open &= ~__ballot(complete);
+        if (!open) break;
+      }
       const unsigned long long turned = rot ? ((open >> rot) | (open << (64u - rot))) : open;
       const uint32_t pick = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__builtin_ctzll(turned) + rot) & 63u));
-      sum_tiles_helping(a, (gb + pick) << a.group_shift, per_group, lane, tile * 7u + pick, help, c, s);
+      sum_tiles_helping(a, (gb + pick) << a.group_shift, per_group, lane, tile * 7u + pick, help, c, s, first_mover_rule, tile);
       open &= ~(1ull << pick);
+      walked = true;
     }
   }
   base_count = c;
@@ -621,7 +736,7 @@ __device__ __forceinline__ void resolve_prefix_unaided(const A& a, uint32_t tile
 // `help(u)`: the aggregate {sum : 32 | count : 32} of tile u computed from its inputs by the calling wave.
 template <class A, class Help>
 __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32_t lane,
-                                               uint32_t& base_count, uint32_t& base_sum, Help help) {
+                                               uint32_t& base_count, uint32_t& base_sum, Help help, bool first_mover_rule = false) {
   const uint32_t group = tile >> a.group_shift;
   const uint32_t group_first = group << a.group_shift;
   const uint32_t r = tile - group_first;  // earlier tiles of the own group (< 64)
@@ -643,12 +758,15 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
   bool ready0 = !v0, ready1 = !v1, ready2 = !v2;
   uint32_t c = 0, s = 0, polls = 0;
   for (;;) {
+    bool not_started = false;
     if (!ready0) {
       const unsigned long long g = status_load(e0);
       if (granule_ready(a, g)) {
         ready0 = true;
         c += (uint32_t)g & ((1u << kTileCountBits) - 1u);
         s += (uint32_t)(g >> 32);
+      } else {
+        not_started = first_mover_rule && !granule_of_this_launch(a, g);
       }
     }
     if (!ready1) {
@@ -668,14 +786,16 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
       }
     }
     const bool all = ready0 && ready1 && ready2;
-#ifdef MIP_DEBUG_STAMPS
+#if defined(MIP_DEBUG_STAMPS) && !defined(MIP_EXP_HELP_STAMPS)
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] += 1;
     if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] += (unsigned long long)__popcll(__ballot(!all));
 #endif
     if (__all(all)) break;
     // Patience in proportion: a handful of words missing are contemporaries that publish in a moment (the full budget); dozens
     // missing are workgroups that have not started — waiting for those buys nothing, and every waiting wave waits the same.
-    const uint32_t budget = (uint32_t)__popcll(__ballot(!all)) > 8u ? kImpatientPolls : kPatientPolls;
+    // ... and a predecessor whose workgroup has not even started (its granule is not marked STARTED: mark_tile_started) after this
+    // tile has done all of its own arithmetic and looked twice is not going to publish in a moment either
+    const uint32_t budget = (uint32_t)__popcll(__ballot(!all)) > 8u ? kImpatientPolls : (__any(not_started) ? kNotStartedPolls : kPatientPolls);
     if (__builtin_expect(++polls > budget, 0)) {  // scalar: wave-uniform
       ok = false;
       break;
@@ -686,7 +806,7 @@ __device__ __forceinline__ void resolve_prefix(const A& a, uint32_t tile, uint32
     base_count = wave_sum(c);
     base_sum = wave_sum(s);
   } else {
-    resolve_prefix_unaided(a, tile, lane, help, base_count, base_sum);
+    resolve_prefix_unaided(a, tile, lane, help, base_count, base_sum, first_mover_rule);
   }
   if (r == 0u && group > 0u && lane == 0u) {  // first tile of a group: publish the group's start
     unsigned long long* p = &a.start1[2 * (size_t)group];
@@ -883,6 +1003,7 @@ __device__ __forceinline__ unsigned long long help_tile_aggregate(uint32_t u, ui
   const uint32_t n = ka->n;
   struct { const float* box_override; } box_args = {ka->box_override};
   uint32_t cnt = 0, sum = 0;
+// (unrolled 2x / 4x: a help takes 13.7 / 12.4 us instead of 14.1 at 2.5 M in scrambled order, the launch the same: not kept)
 #pragma nounroll
   for (uint32_t w = 0; w < kWaves; ++w) {
     const uint32_t j = u * kTile + w * 64u + lane;
@@ -909,8 +1030,9 @@ __device__ __forceinline__ unsigned long long help_tile_aggregate(uint32_t u, ui
   return ((unsigned long long)sum << 32) | cnt;
 }
 
-// Tile aggregate assembled in LDS by the four waves: {Σ index_len : 32 | arrivals : 8 | - : 8 | count : 16}.
+// Tile aggregate assembled in LDS by the four waves: {Σ index_len : 32 | arrivals : 8 | - : 7 | helped first : 1 | count : 16}.
 constexpr uint32_t kAggArrivalShift = 24;
+constexpr uint32_t kAggHelpedFirst = 1u << 16;  // a helping wave adds this tile to its group's accumulator (mark_tile_started)
 
 // kBoxOverride: every instance brings its own mesh-space box (KernelArgs.box_override; the skinned
 // extension).
@@ -933,8 +1055,12 @@ constexpr uint32_t kAggArrivalShift = 24;
 // kWire: 1 = the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above), 2 = in its
 // packed form (MIP_OUT_WIRE_PACKED, wire_packed_copy_out; KernelArgs.wire_index_bits); 0 = 20-byte commands. A template
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
-template <bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0>
+// kFirstMover: the launch follows the first-mover rule (KernelArgs::kFirstMoverAdds above; the host launches this instantiation
+// when KernelArgs.first_mover_rule == 1). An instantiation of its own: as a run-time flag the rule's branches and the registers
+// they keep alive cost the ordinary launch 0.05-0.3 us (profiles/r05_first_mover_ab.txt).
+template <bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0, bool kFirstMover = false>
 __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
+  static_assert(!kFirstMover || KernelArgs::kFirstMoverAdds, "this build has no first-mover rule");
   static_assert(kOrder == 1 || kOrder == 3, "unknown order");
   static_assert(!kWire || !kBoxOverride, "skinned frames do not emit the wire form");
   static_assert(kGeneral || !kBoxOverride, "a box override may be non-finite");
@@ -960,6 +1086,14 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const bool active = i < a.n;
   const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
   MIP_STAMP(0);
+#ifdef MIP_DEBUG_STAMPS
+  // fault injection (diagnostic build only): one tile never marks itself started and never publishes, so the later tiles have
+  // to compute that tile's aggregate themselves (resolve_prefix) — and the launch must end with the right bytes
+  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
+#else
+  const bool skip_publish = false;
+#endif
+  unsigned long long granule_before = 0;
 
   // ---- the frame: kernel arguments, or (recorded launches) 128 B of device memory read by the
   //      first 32 lanes of every wave and broadcast, in flight together with the instance loads ----
@@ -999,6 +1133,13 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // (a copy of small mesh tables in LDS was measured: no gain — profiles/r02_lds_pad_occupancy_and_mesh_cache_ab.txt)
   const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
   const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  // this tile is running (launches that follow the first-mover rule). Wherever in the tile's head the swap is issued — first of
+  // all, behind the instance loads, behind the mesh-table gather — it costs the launch 0.3 us: loads and returning atomics come
+  // back in the order they were issued, and this one takes longer than a load (profiles/r05_first_mover_ab.txt)
+  constexpr bool first_mover_rule = kFirstMover;
+  const bool marks = first_mover_rule && want_cmds && tid == 63u && !skip_publish;  // (a lane that publishes for wave 0)
+  if constexpr (first_mover_rule)
+    if (want_cmds) granule_before = mark_tile_started_issue(a, tile, marks);
   MeshEntry mb;
   mb.min_x = mb0.x; mb.min_y = mb0.y; mb.min_z = mb0.z; mb.len0 = __float_as_uint(mb0.w);
   mb.max_x = mb1.x; mb.max_y = mb1.y; mb.max_z = mb1.z; mb.len1 = __float_as_uint(mb1.w);
@@ -1032,23 +1173,18 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const unsigned long long vis_mask = __ballot(visible);
   const uint32_t rank_in_wave = lanes_below(keep_mask);
   const uint32_t incl_sum = wave_inclusive_scan(len_vis);
-#ifdef MIP_DEBUG_STAMPS
-  // fault injection (diagnostic build only): one tile never publishes, so every later tile has to compute
-  // that tile's aggregate itself (resolve_prefix) — and the launch must end with the right bytes
-  const bool skip_publish = a.debug_skip_publish_tile == tile + 1u;
-#else
-  const bool skip_publish = false;
-#endif
   if (want_cmds && lane == 63u) {
     const uint32_t wc = (uint32_t)__popcll(keep_mask);
     s_wave_count[wave] = wc;
     s_wave_sum[wave] = incl_sum;
-    const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | wc;
+    // (wave 0 brings what mark_tile_started answered: whichever wave arrives last publishes)
+    const bool helped_first = marks && mark_tile_started_answer(a, granule_before);
+    const unsigned long long mine = ((unsigned long long)incl_sum << 32) | (1ull << kAggArrivalShift) | (helped_first ? kAggHelpedFirst : 0u) | wc;
     const unsigned long long all = __hip_atomic_fetch_add(&s_tile_agg, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + mine;
     // Published before any bulk store of this wave and without waiting for a barrier: the
     // successors' look-ups depend on it, nothing else does.
     bool publish = ((uint32_t)all >> kAggArrivalShift) == kWaves && !skip_publish;
-    if (publish) publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32));
+    if (publish) publish_aggregate(a, tile, (uint32_t)all & 0xffffu, (uint32_t)(all >> 32), !((uint32_t)all & kAggHelpedFirst));
   }
   // ---- stage the matrix rows for the transposed store (three conflict-free ds_write_b128, 48-B pitch) ----
   if (a.model || a.tlas_instances) {
@@ -1154,7 +1290,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     if (wave != 0) return;
     store_aabb();  // wave 0's own (optional) boxes go out before the look-up: nothing of the instance lives across it
     uint32_t base_count = 0, base_sum = 0;
-    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help);
+    if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help, first_mover_rule);
+    else note_helps_for_the_host(a, lane);
     if (lane == 0 && tile == a.n_tiles - 1u) {
       *a.draw_count = base_count + tile_count;
       if (a.index_total) *a.index_total = base_sum + tile_sum;
@@ -1232,7 +1369,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   store_aabb();  // (optional output) before the look-up: nothing of the instance lives across it
   uint32_t base_count = 0, base_sum = 0;
 #ifndef MIP_EXP_NO_HOP  // tuning builds only: what the kernel costs without the cross-tile look-up (results are wrong)
-  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help);
+  if (tile > 0) resolve_prefix(a, tile, lane, base_count, base_sum, help, first_mover_rule);
+  else note_helps_for_the_host(a, lane);
 #else
   base_count = tile * 64u;
 #ifdef MIP_EXP_FAKE_DELAY  // idle for the time a look-up takes, without its memory traffic

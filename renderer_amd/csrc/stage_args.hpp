@@ -187,6 +187,7 @@ void launch_skinned_bounds(uint32_t blocks, hipStream_t stream, const SkinArgs& 
 constexpr uint32_t kMaxViews = 4;
 
 struct ViewArgs {
+  static constexpr bool kFirstMoverAdds = false;  // only owners add to a view's group accumulators (KernelArgs has the other rule)
   // prefix state of this view (publish_aggregate / resolve_prefix read these names)
   unsigned long long* status0;
   unsigned long long* acc1;
@@ -232,6 +233,6 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // ---- rows a-1 .. a-7, commands-first order (kOrder == 3 of instance_kernel.hpp: launches below ~0.9 M instances) ----
 // The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in api_frame.hip.
 using FrameKernelFn = void (*)(const KernelArgs);
-FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */);
+FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */, bool first_mover);
 
 }  // namespace mip

@@ -101,16 +101,18 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 // an instantiation referenced from both units would be registered twice under one host stub.
 namespace {
 template <bool kBox, bool kGeneral, int kWire>
-FrameKernelFn commands_first() {
+FrameKernelFn commands_first(bool first_mover) {
+  if constexpr (KernelArgs::kFirstMoverAdds)
+    if (first_mover) return (FrameKernelFn)mip_instance_pipeline_kernel<kBox, kGeneral, 3, kWire, true>;
   return (FrameKernelFn)mip_instance_pipeline_kernel<kBox, kGeneral, 3, kWire>;
 }
 }  // namespace
 
-FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire) {
-  if (box_override) return commands_first<true, true, 0>();  // skinned frames: always general, never wire
-  if (wire == 2) return general ? commands_first<false, true, 2>() : commands_first<false, false, 2>();
-  if (wire == 1) return general ? commands_first<false, true, 1>() : commands_first<false, false, 1>();
-  return general ? commands_first<false, true, 0>() : commands_first<false, false, 0>();
+FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire, bool first_mover) {
+  if (box_override) return commands_first<true, true, 0>(first_mover);  // skinned frames: always general, never wire
+  if (wire == 2) return general ? commands_first<false, true, 2>(first_mover) : commands_first<false, false, 2>(first_mover);
+  if (wire == 1) return general ? commands_first<false, true, 1>(first_mover) : commands_first<false, false, 1>(first_mover);
+  return general ? commands_first<false, true, 0>(first_mover) : commands_first<false, false, 0>(first_mover);
 }
 
 }  // namespace mip

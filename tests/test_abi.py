@@ -152,3 +152,19 @@ def test_rust_binding_sizes_and_symbols_follow_the_header():
     # every call the shim text makes is declared in the binding
     shim = open(os.path.join(ROOT, "integration", "rust", "instance_pipeline.rs")).read()
     assert set(re.findall(r"mip_sys::(mip_[a-z_]+)\(", shim)) <= rust_fns
+
+
+def test_no_instruction_touches_the_registers_of_the_pending_started_swap(tmp_path):
+    """The frame kernel issues its STARTED swap from inline assembly and asks for the answer hundreds of instructions later
+    (instance_kernel.hpp, mark_tile_started_issue / _answer): the compiler does not know the destination registers are pending.
+    The gfx950 ISA of every kernel that carries the swap, generated with the product's flags (make asm), is checked: nothing
+    reads, writes or spills them in between."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "renderer_amd", "csrc"), "asm-frame", f"ASM_DIR={tmp_path}"], check=True,
+                   capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_pending_swap.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 violations" in r.stdout and not r.stdout.startswith("0 pending"), r.stdout

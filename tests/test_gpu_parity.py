@@ -473,7 +473,7 @@ def frame_case(n, order, wire=False, nonfinite=False):
         bitmap = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=dev)
         scal = torch.zeros(8, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        for rep in range(2):
+        for rep in range(4):   # (launches that had to help make the ones after the next follow the first-mover rule: both kinds run)
             p.run_device(make_frame(s["planes"], s["cam_pos"]), visible_bitmap=bitmap.data_ptr(), draw_cmds=cmds.data_ptr(),
                          draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4, wire=wire)
             count = int(scal[0].item())
@@ -566,15 +566,19 @@ def _run_order_child(what, **env_add):
     return [int(x) for x in line[0].split()[1:]]
 
 
-@pytest.mark.parametrize("tile_order", ["reverse", "scramble"])
-def test_any_dispatch_order_gives_the_same_bytes(tile_order):
+@pytest.mark.parametrize("tile_order,first_mover", [("reverse", None), ("scramble", None), ("scramble", "always"), ("scramble", "never")])
+def test_any_dispatch_order_gives_the_same_bytes(tile_order, first_mover):
     """No kernel of the library depends on the order the hardware starts workgroups in. The diagnostic build numbers
     the tiles by a PERMUTATION of the workgroup index — reversed (the first workgroups to run are the LAST tiles, every
     one of which needs every earlier tile), or scrambled: a tile whose predecessors have not published after the
     patient polls computes their aggregates itself (instance_kernel.hpp, resolve_prefix). Command list, count, index
     total and bitmap equal the oracle's, in both kernel orders, both wire forms, with non-finite instances, for a
-    launch that is resident as a whole (nothing to help) and for one that is not (thousands of helps)."""
-    helps = _run_order_child("frames", MIP_DEBUG_TILE_ORDER=tile_order)
+    launch that is resident as a whole (nothing to help) and for one that is not (thousands of helps).
+    Three frames each: the first finds the state of an ordinary launch (only a tile's owner adds it to its group's accumulator),
+    the later ones follow the first-mover rule because their predecessor had to help (mark_tile_started: tiles mark themselves
+    STARTED, the first to touch a granule adds the tile); MIP_TUNE_FIRST_MOVER pins either rule for every frame."""
+    env = {"MIP_TUNE_FIRST_MOVER": first_mover} if first_mover else {}
+    helps = _run_order_child("frames", MIP_DEBUG_TILE_ORDER=tile_order, **env)
     # 32 tiles, all resident: the predecessors normally publish within the patient polls (0 helps); a cold first launch makes some
     # late (round 4: 34 on the builder's box, 91 on the driver's). 3 907 tiles: the early workgroups normally help themselves.
     # How many is a timing property — reported; the bytes the child compared are the test.
@@ -590,11 +594,13 @@ def test_any_dispatch_order_recorded_graphs_skinned_and_views():
         report_timing_property(f"{what}, tiles reversed: helps", helps, "> 0", helps[-1] > 0)
 
 
-def test_a_tile_that_never_publishes_is_helped():
+@pytest.mark.parametrize("first_mover", [None, "always"])
+def test_a_tile_that_never_publishes_is_helped(first_mover):
     """Fault injection (diagnostic build): tile 5 never publishes its aggregate (rounds 1-3: every later tile's bounded
     wait expired after 0.5 s and the frame ended in MIP_ERR_TIMEOUT). Now the tiles that need it compute it: right
     outputs, no error, and the count of helps says it happened."""
-    helps = _run_order_child("frames", MIP_DEBUG_SKIP_PUBLISH_TILE="5")
+    env = {"MIP_TUNE_FIRST_MOVER": first_mover} if first_mover else {}
+    helps = _run_order_child("frames", MIP_DEBUG_SKIP_PUBLISH_TILE="5", **env)
     assert all(h > 0 for h in helps), helps
 
 
