@@ -76,7 +76,7 @@ struct KernelArgs {
   // The first-mover rule (mark_tile_started): a tile's workgroup marks its granule STARTED when it starts, and whoever moves a
   // granule from an earlier launch's value to this launch's — the owner, or a wave that computes the tile for it — adds the tile
   // to its group's accumulator, so that groups complete without their owners. The mark is a returning device-scope atomic at the
-  // head of every tile: +0.3 us per launch whether anybody helps or not (profiles/r05_first_mover_ab.txt), so a launch follows
+  // head of every tile: +0.3 us per launch whether anybody helps or not (profiles/r05_first_mover.txt), so a launch follows
   // the rule only when recent launches had to help (`first_mover_rule`: note_helps_for_the_host), or when told to.
 #ifndef MIP_FIRST_MOVER_ADDS  // 0: A/B builds only (tools/r05_first_mover.sh) — the rule of rounds 3-4 whatever happens
 #define MIP_FIRST_MOVER_ADDS 1
@@ -84,7 +84,7 @@ struct KernelArgs {
   static constexpr bool kFirstMoverAdds = MIP_FIRST_MOVER_ADDS != 0;
   // ---- what every wave of every tile reads before its first instruction that depends on memory: 184 bytes = three 64-byte lines
   //      of the argument block (with the fields in the order they were added, these were spread over five lines; one line more in
-  //      front of the planes cost a 100 k launch 0.15 us: profiles/r05_first_mover_ab.txt) ----
+  //      front of the planes cost a 100 k launch 0.15 us: profiles/r05_first_mover.txt) ----
   const float* pos;             // n*3
   const float4* rot;            // n  [i,j,k,w]
   const float* scale;           // n
@@ -1057,7 +1057,7 @@ constexpr uint32_t kAggHelpedFirst = 1u << 16;  // a helping wave adds this tile
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
 // kFirstMover: the launch follows the first-mover rule (KernelArgs::kFirstMoverAdds above; the host launches this instantiation
 // when KernelArgs.first_mover_rule == 1). An instantiation of its own: as a run-time flag the rule's branches and the registers
-// they keep alive cost the ordinary launch 0.05-0.3 us (profiles/r05_first_mover_ab.txt).
+// they keep alive cost the ordinary launch 0.05-0.3 us (profiles/r05_first_mover.txt).
 template <bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0, bool kFirstMover = false>
 __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
   static_assert(!kFirstMover || KernelArgs::kFirstMoverAdds, "this build has no first-mover rule");
@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
   // this tile is running (launches that follow the first-mover rule). Wherever in the tile's head the swap is issued — first of
   // all, behind the instance loads, behind the mesh-table gather — it costs the launch 0.3 us: loads and returning atomics come
-  // back in the order they were issued, and this one takes longer than a load (profiles/r05_first_mover_ab.txt)
+  // back in the order they were issued, and this one takes longer than a load (profiles/r05_first_mover.txt)
   constexpr bool first_mover_rule = kFirstMover;
   const bool marks = first_mover_rule && want_cmds && tid == 63u && !skip_publish;  // (a lane that publishes for wave 0)
   if constexpr (first_mover_rule)
