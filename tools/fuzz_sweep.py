@@ -58,6 +58,10 @@ for seed in range(first, first + seeds):
     os.environ.pop("MIP_TUNE_THREE_PASS_MIN_TILES", None)
     if ordered and seed % 8 == 1:
         os.environ["MIP_TUNE_THREE_PASS_MIN_TILES"] = "0"
+    # round 5: a third of the seeds with the frame kernel's first-mover instantiation for every launch (read at context creation)
+    os.environ.pop("MIP_TUNE_FIRST_MOVER", None)
+    if seed % 3 == 2:
+        os.environ["MIP_TUNE_FIRST_MOVER"] = "always"
     with ra.InstancePipeline(max_instances=max(n, 1), max_meshes=64, frames_in_flight=int(rng.integers(1, 4)), ordered_tiles=ordered) as p:
         p.set_mesh_table(s["meshes"])
         p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
