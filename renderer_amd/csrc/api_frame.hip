@@ -295,9 +295,9 @@ int32_t run_frame(MipContext* ctx, const MipFrame* frame, const MipOutputs* out,
       MIP_HIP(ctx, hipGetLastError());
     }
     {
-      void* params[1] = {&a};
+      mip::FrameKernelParams params(a);
       if (plan.general) ctx->timings.general_launches += 1;
-      MIP_HIP(ctx, hipLaunchKernel((const void*)frame_kernel_of(plan, a.first_mover_rule == 1u), dim3(plan.n_tiles), dim3(mip::kTile), params, ctx->lds_pad, stream));
+      MIP_HIP(ctx, hipLaunchKernel((const void*)frame_kernel_of(plan, a.first_mover_rule == 1u), dim3(plan.n_tiles), dim3(mip::kTile), params.p, ctx->lds_pad, stream));
     }
     if (plan.tri != mip::TriangleKernel::none) {
       mip::TriangleArgs t{};
@@ -611,7 +611,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           fill_kernel_args(ctx, sl, &blank, out, true, a);
           a.frame_ring = sl.d_frame_ring + (size_t)j * mip::kFrameWords;
           a.epoch = base + 1 + j;
-          void* params[1] = {&a};
+          mip::FrameKernelParams params(a);
           hipKernelNodeParams kp{};
           const mip::LaunchPlan plan = mip::plan_frame(plan_state(ctx), plan_request(out, false));  // validated by mip_run_many
           a.group_shift = plan.group_shift;
@@ -619,7 +619,7 @@ static int32_t run_many_graphed(MipContext* ctx, const MipFrame* frames, uint32_
           kp.gridDim = dim3(plan.n_tiles);
           kp.blockDim = dim3(mip::kTile);
           kp.sharedMemBytes = ctx->lds_pad;
-          kp.kernelParams = params;
+          kp.kernelParams = params.p;
           kp.extra = nullptr;
           hipGraphNode_t node = nullptr;
           MIP_HIP(ctx, hipGraphAddKernelNode(&node, fg.graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));

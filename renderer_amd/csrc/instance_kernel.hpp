@@ -139,6 +139,11 @@ struct KernelArgs {
 #endif
 };
 
+// The frame kernel's leading scalar arguments (MIP_FRAME_HEAD_PARAMS, at the kernel): 6 pointers + n, padded to the block's
+// alignment — where KernelArgs starts in the kernarg segment.
+constexpr uint32_t kFrameHeadBytes = 56;
+static_assert(alignof(KernelArgs) == 8 && 6 * sizeof(void*) + sizeof(uint32_t) <= kFrameHeadBytes && kFrameHeadBytes % alignof(KernelArgs) == 0, "argument layout");
+
 // Device-side image of a frame for recorded launches: 32 words (128 B).
 //   [0..23] planes, [24..26] cam_pos, [27] first_instance_base, [28] first_index_base, [29..31] pad
 constexpr uint32_t kFrameWords = 32;
@@ -962,10 +967,11 @@ __device__ __forceinline__ bool lod_is_far(const float (&cam)[3], float px, floa
 // scalar registers) would keep them alive across the whole kernel: measured, the allocator then parks them in vector-
 // register lanes — ~50 v_writelane / s_mov at the head of every workgroup, 1 M instances 18.65 -> 19.3 us. Reloading
 // costs the hot path nothing.
-template <class Args>
+template <class Args, uint32_t kSkipBytes = 0>
 __device__ __forceinline__ const __attribute__((address_space(4))) Args* cold_kernel_args() {
   typedef const __attribute__((address_space(4))) Args* Ptr;
-  Ptr p = (Ptr)__builtin_amdgcn_kernarg_segment_ptr();  // the kernels here take ONE argument, by value: it starts the segment
+  // (the views kernel takes ONE argument, by value: it starts the segment; the frame kernel's block follows its leading scalars)
+  Ptr p = (Ptr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + kSkipBytes);
   asm volatile("" : "+s"(p));
   return p;
 }
@@ -992,7 +998,7 @@ __device__ __forceinline__ void cold_frame(const __attribute__((address_space(4)
 // within kPatientPolls gets here (resolve_prefix).
 template <bool kBoxOverride, bool kGeneral>
 __device__ __forceinline__ unsigned long long help_tile_aggregate(uint32_t u, uint32_t lane) {
-  const auto* ka = cold_kernel_args<KernelArgs>();
+  const auto* ka = cold_kernel_args<KernelArgs, kFrameHeadBytes>();
   float planes[24], cam[3];
   cold_frame(ka, planes, cam);
   const float* pos = ka->pos;
@@ -1055,11 +1061,21 @@ constexpr uint32_t kAggHelpedFirst = 1u << 16;  // a helping wave adds this tile
 // kWire: 1 = the tile's commands leave in the wire form of a shard's draw list (MIP_OUT_WIRE, wire_copy_out above), 2 = in its
 // packed form (MIP_OUT_WIRE_PACKED, wire_packed_copy_out; KernelArgs.wire_index_bits); 0 = 20-byte commands. A template
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
+// The kernel's arguments: what a tile needs before it can issue its first load — the input arrays, the tables, the command
+// pointer (is there a prefix at all) and n — as LEADING SCALAR arguments, 13 dwords (a wave has 16 user SGPRs, two of them the
+// kernarg segment's address: 14 can be preloaded), which the dispatcher preloads into SGPRs
+// (-mllvm -amdgpu-kernarg-preload-count=16: Makefile) before the wave's first instruction; then the argument block. Inside the
+// block the same values were a scalar load from the kernarg segment and a wait — a round trip in front of every tile's instance
+// loads (profiles/r05_tile_head.txt). The block keeps its copies: the cold path (help_tile_aggregate) and the late uses read those.
+#define MIP_FRAME_HEAD_PARAMS                                                                                              \
+  const float* __restrict__ h_pos, const float4* __restrict__ h_rot, const float* __restrict__ h_scale,                    \
+      const uint32_t* __restrict__ h_mesh_id, const MeshEntry* __restrict__ h_meshes, uint32_t* h_cmds, uint32_t h_n
+
 // kFirstMover: the launch follows the first-mover rule (KernelArgs::kFirstMoverAdds above; the host launches this instantiation
 // when KernelArgs.first_mover_rule == 1). An instantiation of its own: as a run-time flag the rule's branches and the registers
 // they keep alive cost the ordinary launch 0.05-0.3 us (profiles/r05_first_mover.txt).
 template <bool kBoxOverride, bool kGeneral, int kOrder, int kWire = 0, bool kFirstMover = false>
-__global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void mip_instance_pipeline_kernel(MIP_FRAME_HEAD_PARAMS, const KernelArgs a) {
   static_assert(!kFirstMover || KernelArgs::kFirstMoverAdds, "this build has no first-mover rule");
   static_assert(kOrder == 1 || kOrder == 3, "unknown order");
   static_assert(!kWire || !kBoxOverride, "skinned frames do not emit the wire form");
@@ -1076,15 +1092,15 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   __shared__ unsigned long long s_tile_agg;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const bool want_cmds = a.cmds != nullptr;
+  const bool want_cmds = h_cmds != nullptr;
   uint32_t tile = blockIdx.x;
 #ifdef MIP_DEBUG_STAMPS
   if (a.debug_tile_mult) tile = (uint32_t)(((unsigned long long)blockIdx.x * a.debug_tile_mult + a.debug_tile_add) % a.n_tiles);
 #endif
   const uint32_t tile_first = tile * kTile;
   const uint32_t i = tile_first + tid;
-  const bool active = i < a.n;
-  const uint32_t il = active ? i : a.n - 1u;  // keep the loads of idle lanes in bounds
+  const bool active = i < h_n;
+  const uint32_t il = active ? i : h_n - 1u;  // keep the loads of idle lanes in bounds
   MIP_STAMP(0);
 #ifdef MIP_DEBUG_STAMPS
   // fault injection (diagnostic build only): one tile never marks itself started and never publishes, so the later tiles have
@@ -1095,6 +1111,13 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
 #endif
   unsigned long long granule_before = 0;
 
+  // ---- loads: 36 B per instance. FIRST, from preloaded arguments: nothing is waited for in front of them. (Behind the frame
+  //      below, with the pointers in the argument block, the compiler fetched `frame_ring`, waited, branched on it, and only then
+  //      fetched the pointers: two scalar round trips in front of the first instance load. The planes now arrive under the loads.) ----
+  const float px = h_pos[3 * (size_t)il + 0], py = h_pos[3 * (size_t)il + 1], pz = h_pos[3 * (size_t)il + 2];
+  const float4 q = h_rot[il];
+  const float sc = h_scale[il];
+  const uint32_t mesh = h_mesh_id[il];
   // ---- the frame: kernel arguments, or (recorded launches) 128 B of device memory read by the
   //      first 32 lanes of every wave and broadcast, in flight together with the instance loads ----
   float planes[24], cam[3];
@@ -1119,11 +1142,6 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   // a predecessor that does not publish is not waited for: this wave computes its aggregate itself (resolve_prefix)
   auto help = [lane](uint32_t u) { return help_tile_aggregate<kBoxOverride, kGeneral>(u, lane); };
 
-  // ---- loads: 36 B per instance ----
-  const float px = a.pos[3 * (size_t)il + 0], py = a.pos[3 * (size_t)il + 1], pz = a.pos[3 * (size_t)il + 2];
-  const float4 q = a.rot[il];
-  const float sc = a.scale[il];
-  const uint32_t mesh = a.mesh_id[il];
   // the LDS word the waves add their aggregates to; the barrier does not wait for the instance
   // loads above, and every wave of the workgroup has only just started
   if (want_cmds) {
@@ -1131,8 +1149,8 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     __syncthreads();
   }
   // (a copy of small mesh tables in LDS was measured: no gain — profiles/r02_lds_pad_occupancy_and_mesh_cache_ab.txt)
-  const float4 mb0 = *reinterpret_cast<const float4*>(&a.meshes[mesh].min_x);
-  const float4 mb1 = *reinterpret_cast<const float4*>(&a.meshes[mesh].max_x);
+  const float4 mb0 = *reinterpret_cast<const float4*>(&h_meshes[mesh].min_x);
+  const float4 mb1 = *reinterpret_cast<const float4*>(&h_meshes[mesh].max_x);
   // this tile is running (launches that follow the first-mover rule). Wherever in the tile's head the swap is issued — first of
   // all, behind the instance loads, behind the mesh-table gather — it costs the launch 0.3 us: loads and returning atomics come
   // back in the order they were issued, and this one takes longer than a load (profiles/r05_first_mover.txt)

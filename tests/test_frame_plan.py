@@ -25,5 +25,5 @@ def test_plan_header_has_no_hip_dependency():
     assert "hip/" not in text and "__device__" not in text and "__global__" not in text
     api = open(os.path.join(ROOT, "renderer_amd", "csrc", "api_frame.hip")).read()
     # the launch code takes the kernel, the grids and the scratch from the plan
-    for field in ("plan.n_tiles", "plan.tri_blocks", "plan.recompact_blocks", "plan.skin_blocks", "frame_kernel_of(plan)", "plan.need_tri_scratch"):
+    for field in ("plan.n_tiles", "plan.tri_blocks", "plan.recompact_blocks", "plan.skin_blocks", "frame_kernel_of(plan, ", "plan.need_tri_scratch"):
         assert field in api, field
