@@ -223,6 +223,7 @@ int32_t mip_create(const MipConfig* cfg, MipContext** out) {
     MIP_HIP(ctx, hipMemset(ctx->d_stamps, 0, tiles_cap * 64));
 #endif
     if (const char* env = std::getenv("MIP_TUNE_LDS_PAD")) ctx->lds_pad = (uint32_t)std::atoi(env);
+    ctx->no_one_mesh = std::getenv("MIP_TUNE_NO_ONE_MESH") != nullptr;
     if (const char* env = std::getenv("MIP_TUNE_FIRST_MOVER"))  // the frame kernel's first-mover rule: always | never | (default) when the previous launch helped
       ctx->first_mover_env = std::strcmp(env, "always") == 0 ? 1u : (std::strcmp(env, "never") == 0 ? 2u : 0u);
     if (const char* env = std::getenv("MIP_TUNE_TRI_BLOCK_THREADS")) {

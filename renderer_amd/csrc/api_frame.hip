@@ -115,6 +115,7 @@ void fill_kernel_args(MipContext* ctx, MipContext::FrameSlot& sl, const MipFrame
   a.n = n;
   a.bitmap_words = (n + 31u) / 32u;
   a.n_meshes = ctx->m;
+  a.one_mesh = ctx->m == 1u && !ctx->no_one_mesh ? 1u : 0u;
   a.wire_index_bits = mip_wire_index_bits(ctx->m);
   a.first_instance_base = frame->first_instance_base;
   a.first_index_base = frame->first_index_base;

@@ -124,6 +124,7 @@ struct MipContext {
   uint32_t acc1_offset_words = 0, start1_offset_words = 0, helps_seen_offset_words = 0, groups_cap = 0;
   // the frame kernel's first-mover rule (instance_kernel.hpp, KernelArgs.first_mover_rule): followed by the launches that come
   // after a launch whose tile 0 saw new helps (it writes the count to h_error[kHelpHintWord])
+  bool no_one_mesh = false;               // MIP_TUNE_NO_ONE_MESH: a one-entry mesh table is gathered from like any other (A/B runs, tests of that path)
   uint32_t first_mover_env = 0;           // MIP_TUNE_FIRST_MOVER=always|never -> 1|2, read at context creation; 0: as the hints say
   uint32_t help_hint_seen = 0;            // the hint word's value when the host last looked
   uint32_t first_mover_launches_left = 0; // launches that still follow the rule

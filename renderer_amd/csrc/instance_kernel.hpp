@@ -122,6 +122,7 @@ struct KernelArgs {
   const unsigned long long* blas_address;  // m, BLAS device address per mesh (with tlas_instances)
   const float* box_override;    // n*8 or null: per-instance mesh-space box {min xyz, -, max xyz, -} that replaces the mesh table's (skinned instances)
   uint32_t wire_index_bits;     // MIP_OUT_WIRE_PACKED: bits of a record that hold the instance index (mesh id above them, LOD in bit 31)
+  uint32_t one_mesh;            // 1: the mesh table has one entry (the kernel's leading argument h_one_mesh)
   uint32_t first_mover_rule;    // 1: this launch follows the first-mover rule (the host's choice: api_frame.hip, MIP_TUNE_FIRST_MOVER)
   uint32_t* error_flag;         // host-mapped error words
   uint32_t* help_counter;       // DEVICE memory: tile aggregates that waiting tiles computed themselves (MipTimings.prefix_helps), kHelpShards words
@@ -139,10 +140,10 @@ struct KernelArgs {
 #endif
 };
 
-// The frame kernel's leading scalar arguments (MIP_FRAME_HEAD_PARAMS, at the kernel): 6 pointers + n, padded to the block's
+// The frame kernel's leading scalar arguments (MIP_FRAME_HEAD_PARAMS, at the kernel): 6 pointers, n, one_mesh — to the block's
 // alignment — where KernelArgs starts in the kernarg segment.
 constexpr uint32_t kFrameHeadBytes = 56;
-static_assert(alignof(KernelArgs) == 8 && 6 * sizeof(void*) + sizeof(uint32_t) <= kFrameHeadBytes && kFrameHeadBytes % alignof(KernelArgs) == 0, "argument layout");
+static_assert(alignof(KernelArgs) == 8 && 6 * sizeof(void*) + 2 * sizeof(uint32_t) <= kFrameHeadBytes && kFrameHeadBytes % alignof(KernelArgs) == 0, "argument layout");
 
 // Device-side image of a frame for recorded launches: 32 words (128 B).
 //   [0..23] planes, [24..26] cam_pos, [27] first_instance_base, [28] first_index_base, [29..31] pad
@@ -1062,14 +1063,14 @@ constexpr uint32_t kAggHelpedFirst = 1u << 16;  // a helping wave adds this tile
 // packed form (MIP_OUT_WIRE_PACKED, wire_packed_copy_out; KernelArgs.wire_index_bits); 0 = 20-byte commands. A template
 // parameter, not a run-time flag: as a flag it cost the plain frame 0.2 us at 100 k and at 1 M (profiles/r03_vs_r02_kbench.txt).
 // The kernel's arguments: what a tile needs before it can issue its first load — the input arrays, the tables, the command
-// pointer (is there a prefix at all) and n — as LEADING SCALAR arguments, 13 dwords (a wave has 16 user SGPRs, two of them the
+// pointer (is there a prefix at all), n and whether the mesh table has ONE entry — as LEADING SCALAR arguments, 14 dwords (a wave has 16 user SGPRs, two of them the
 // kernarg segment's address: 14 can be preloaded), which the dispatcher preloads into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16: Makefile) before the wave's first instruction; then the argument block. Inside the
 // block the same values were a scalar load from the kernarg segment and a wait — a round trip in front of every tile's instance
 // loads (profiles/r05_tile_head.txt). The block keeps its copies: the cold path (help_tile_aggregate) and the late uses read those.
 #define MIP_FRAME_HEAD_PARAMS                                                                                              \
   const float* __restrict__ h_pos, const float4* __restrict__ h_rot, const float* __restrict__ h_scale,                    \
-      const uint32_t* __restrict__ h_mesh_id, const MeshEntry* __restrict__ h_meshes, uint32_t* h_cmds, uint32_t h_n
+      const uint32_t* __restrict__ h_mesh_id, const MeshEntry* __restrict__ h_meshes, uint32_t* h_cmds, uint32_t h_n, uint32_t h_one_mesh
 
 // kFirstMover: the launch follows the first-mover rule (KernelArgs::kFirstMoverAdds above; the host launches this instantiation
 // when KernelArgs.first_mover_rule == 1). An instantiation of its own: as a run-time flag the rule's branches and the registers
@@ -1117,7 +1118,19 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
   const float px = h_pos[3 * (size_t)il + 0], py = h_pos[3 * (size_t)il + 1], pz = h_pos[3 * (size_t)il + 2];
   const float4 q = h_rot[il];
   const float sc = h_scale[il];
-  const uint32_t mesh = h_mesh_id[il];
+  // A mesh table of ONE entry (BASELINE configs[1]: 100 k instances of one mesh): every id is 0 (uploads with an id outside the
+  // table are refused) and the entry is the same for every lane — a scalar load issued here, beside the instance loads, instead of
+  // an id load and a gather BEHIND it: one dependent round trip and 4 of the 36 input bytes per instance less.
+  uint32_t mesh = 0;
+  float4 mb0, mb1;
+  if (!h_one_mesh) {
+    mesh = h_mesh_id[il];
+  } else {  // (through the constant address space: a uniform address there is a scalar load; the table is not written during a launch)
+    typedef const __attribute__((address_space(4))) float* ConstWords;
+    ConstWords e = (ConstWords)(unsigned long long)h_meshes;
+    mb0 = make_float4(e[0], e[1], e[2], e[3]);
+    mb1 = make_float4(e[4], e[5], e[6], e[7]);
+  }
   // ---- the frame: kernel arguments, or (recorded launches) 128 B of device memory read by the
   //      first 32 lanes of every wave and broadcast, in flight together with the instance loads ----
   float planes[24], cam[3];
@@ -1149,8 +1162,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? MIP_MIN_WAVES_PER_SIMD : 8) void 
     __syncthreads();
   }
   // (a copy of small mesh tables in LDS was measured: no gain — profiles/r02_lds_pad_occupancy_and_mesh_cache_ab.txt)
-  const float4 mb0 = *reinterpret_cast<const float4*>(&h_meshes[mesh].min_x);
-  const float4 mb1 = *reinterpret_cast<const float4*>(&h_meshes[mesh].max_x);
+  if (!h_one_mesh) {
+    mb0 = *reinterpret_cast<const float4*>(&h_meshes[mesh].min_x);
+    mb1 = *reinterpret_cast<const float4*>(&h_meshes[mesh].max_x);
+  }
   // this tile is running (launches that follow the first-mover rule). Wherever in the tile's head the swap is issued — first of
   // all, behind the instance loads, behind the mesh-table gather — it costs the launch 0.3 us: loads and returning atomics come
   // back in the order they were issued, and this one takes longer than a load (profiles/r05_first_mover.txt)

@@ -232,11 +232,11 @@ void launch_cull_views(bool general, uint32_t tiles, hipStream_t stream, const V
 
 // ---- rows a-1 .. a-7, commands-first order (kOrder == 3 of instance_kernel.hpp: launches below ~0.9 M instances) ----
 // The kernel to hand to hipLaunchKernel; the stores-first order is instantiated in api_frame.hip.
-using FrameKernelFn = void (*)(const float*, const float4*, const float*, const uint32_t*, const MeshEntry*, uint32_t*, uint32_t, const KernelArgs);
+using FrameKernelFn = void (*)(const float*, const float4*, const float*, const uint32_t*, const MeshEntry*, uint32_t*, uint32_t, uint32_t, const KernelArgs);
 // kernelParams of a launch of the frame kernel: its leading scalars are copies of the block's fields (instance_kernel.hpp, MIP_FRAME_HEAD_PARAMS)
 struct FrameKernelParams {
-  void* p[8];
-  explicit FrameKernelParams(KernelArgs& a) : p{&a.pos, &a.rot, &a.scale, &a.mesh_id, &a.meshes, &a.cmds, &a.n, &a} {}
+  void* p[9];
+  explicit FrameKernelParams(KernelArgs& a) : p{&a.pos, &a.rot, &a.scale, &a.mesh_id, &a.meshes, &a.cmds, &a.n, &a.one_mesh, &a} {}
 };
 FrameKernelFn frame_kernel_commands_first(bool box_override, bool general, int wire /* 0 | 1 | 2 = packed */, bool first_mover);
 
