@@ -69,10 +69,6 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
   __shared__ uint32_t s_level[kMaxJoints + 2];                           // per depth: first sorted entry | ceil(2^16/count) << 8
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t J = a.n_joints;
-  // The hierarchy loop below is a chain of short dependent steps; its per-level look-ups come from
-  // LDS (a global or kernarg load per level would put ~1 us of cache latency on that chain).
-  if (tid < J) s_sorted[tid] = a.joints[tid].sorted;
-  if (tid < kMaxJoints + 2u) s_level[tid] = (uint32_t)a.level_start[tid] | ((tid <= kMaxJoints ? a.level_inv[tid] : 0u) << 8);
   const uint32_t ipw = 64u / J, ipb = 4u * ipw;           // instances per wave / workgroup
   const uint32_t block_first = blockIdx.x * ipb;          // < n by the grid size
   const uint32_t in_block = a.n - block_first < ipb ? a.n - block_first : ipb;
@@ -89,6 +85,16 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
   const float4 j0 = jp[0], j1 = jp[1], j2 = jp[2], j3 = jp[3], j4 = jp[4];
   const float ibm[12] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w, j2.x, j2.y, j2.z, j2.w};
   const float box[6] = {j3.x, j3.y, j3.z, j3.w, j4.x, j4.y};
+  // The hierarchy loop below is a chain of short dependent steps; its per-level look-ups come from
+  // LDS (a global or kernarg load per level would put ~1 us of cache latency on that chain). Loaded HERE, behind the pose and
+  // joint loads: in front of them (round 2-4) the workgroup waited for these few words — two dependent round trips — before it
+  // issued the loads its arithmetic waits for (profiles/r05_tile_head.txt, 5).
+  // (unconditional loads at clamped indices, kept in registers: every load of the head is in flight at once, and the words go to
+  //  LDS with the local transforms below)
+  const uint32_t sorted_word = a.joints[tid < J ? tid : 0u].sorted;
+  const uint32_t level_at = tid < kMaxJoints + 2u ? tid : 0u;
+  const uint32_t inv_raw = a.level_inv[level_at <= kMaxJoints ? level_at : 0u];
+  const uint32_t level_word = (uint32_t)a.level_start[level_at] | ((level_at <= kMaxJoints ? inv_raw : 0u) << 8);
 
   // ---- local transform L = T * R * S ----
   float lr[3][3];
@@ -100,6 +106,8 @@ __global__ __launch_bounds__(kSkinBlock) void mip_skinned_bounds_kernel(const Sk
     for (int rr = 0; rr < 3; ++rr) G[c * 3 + rr] = lr[rr][c] * t[7 + c];
   G[9] = t[0]; G[10] = t[1]; G[11] = t[2];
   if (valid) lds_write12(&s_g[pair * 12u], G);
+  if (tid < J) s_sorted[tid] = sorted_word;
+  if (tid < kMaxJoints + 2u) s_level[tid] = level_word;
   __syncthreads();
 
   // ---- hierarchy, one level at a time over the whole workgroup ----
