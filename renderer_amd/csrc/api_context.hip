@@ -311,6 +311,9 @@ int32_t mip_set_mesh_table(MipContext* ctx, const MipMesh* meshes, uint32_t m) {
     MIP_HIP(ctx, hipMemcpyAsync(ctx->d_mesh_draw, draw.data(), m * sizeof(mip::MeshDraw), hipMemcpyHostToDevice, ctx->stream));
     MIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sources are locals
   }
+  // recorded launches carry what follows from the table's SIZE in their arguments (n_meshes, the wire form's index bits, and whether
+  // the one entry of a one-mesh table is read as a scalar: KernelArgs.one_mesh): another size, another recording
+  if (m != ctx->m) ctx->graph_generation++;
   ctx->m = m;
   ctx->have_meshes = true;
   ctx->h_meshes.assign(meshes, meshes + m);

@@ -452,6 +452,51 @@ def test_recorded_graphs_follow_the_census(ra, oracle_mod):
         assert p.timings()["graph_records"] == 3
 
 
+def test_a_mesh_table_that_grows_from_one_entry_rerecords_and_gathers(ra, oracle_mod):
+    """A table of ONE mesh is read as a scalar by the frame kernel (no id load, no gather: KernelArgs.one_mesh), and a recorded
+    launch carries that choice in its arguments. The table growing to two entries and instances moving to the new one must give
+    the oracle's bytes — from direct launches (the gather path, chosen per launch) and from run_many, which has to record again."""
+    import torch
+
+    from renderer_amd.pipeline import make_frame
+
+    s = ra.scene.make_scene(2, n=30_000)   # the one-mesh scene
+    n = s["n"]
+    dev = torch.device("cuda", 0)
+    two = np.concatenate([s["meshes"], ra.scene.mixed_mesh_table()[7:8]])
+    with ra.InstancePipeline(max_instances=n, max_meshes=2, frames_in_flight=2) as p:
+        p.set_mesh_table(s["meshes"])
+        p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+        sets = []
+        for _ in range(2):
+            cmds = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+            scal = torch.zeros(8, dtype=torch.int32, device=dev)
+            sets.append((cmds, scal, p.prepare_outputs(draw_cmds=cmds.data_ptr(), draw_count=scal.data_ptr(), draw_index_total=scal.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        frame = make_frame(s["planes"], s["cam_pos"])
+        outs = [x[2] for x in sets]
+
+        def check(what):
+            want = run_oracle(oracle_mod, s, want=("draw_cmds",))
+            for cmds, scal, _ in sets:
+                c = int(scal[0].item())
+                assert c == want["draw_count"] and cmds[:c].cpu().numpy().tobytes() == want["draw_cmds"].tobytes(), what
+            got = p.run_host(s["planes"], s["cam_pos"])
+            assert_parity(got, run_oracle(oracle_mod, s), what + ", direct launch")
+
+        p.run_many(frame, outs, 64); p.wait()
+        check("one mesh")
+        records = p.timings()["graph_records"]
+        s["meshes"] = two
+        p.set_mesh_table(two)
+        s["mesh_id"] = s["mesh_id"].copy()
+        s["mesh_id"][1000:20_000:3] = 1
+        p.update_instances(0, mesh_id=s["mesh_id"])
+        p.run_many(frame, outs, 64); p.wait()
+        check("two meshes")
+        assert p.timings()["graph_records"] == records + 1
+
+
 @pytest.mark.parametrize("order", [1, 3])
 def test_streamed_outputs_stop_at_the_last_instance(ra, oracle_mod, order, monkeypatch):
     """The matrix and TLAS streams go out through buffer descriptors bounded at the tile's last instance
