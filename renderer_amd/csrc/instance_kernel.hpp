@@ -143,7 +143,7 @@ struct KernelArgs {
 // The frame kernel's leading scalar arguments (MIP_FRAME_HEAD_PARAMS, at the kernel): 6 pointers, n, one_mesh — to the block's
 // alignment — where KernelArgs starts in the kernarg segment.
 constexpr uint32_t kFrameHeadBytes = 56;
-static_assert(alignof(KernelArgs) == 8 && (6 * sizeof(void*) + 2 * sizeof(uint32_t) + 7) / 8 * 8 == kFrameHeadBytes, "argument layout");
+static_assert(alignof(KernelArgs) == 8 && 6 * sizeof(void*) + 2 * sizeof(uint32_t) <= kFrameHeadBytes && kFrameHeadBytes % alignof(KernelArgs) == 0, "argument layout");
 
 // Device-side image of a frame for recorded launches: 32 words (128 B).
 //   [0..23] planes, [24..26] cam_pos, [27] first_instance_base, [28] first_index_base, [29..31] pad

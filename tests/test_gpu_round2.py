@@ -452,6 +452,20 @@ def test_recorded_graphs_follow_the_census(ra, oracle_mod):
         assert p.timings()["graph_records"] == 3
 
 
+@pytest.mark.parametrize("order", [1, 3])
+def test_one_mesh_scene_through_the_gather_path(ra, oracle_mod, order, monkeypatch):
+    """The one-mesh scene with MIP_TUNE_NO_ONE_MESH (read when the context is created): mesh ids loaded and the entry gathered
+    like for any other table — the same bytes as the scalar path the other tests of this scene take."""
+    monkeypatch.setenv("MIP_TUNE_NO_ONE_MESH", "1")
+    monkeypatch.setenv("MIP_TUNE_ORDER", str(order))
+    for n in (1, 300, 100_000):
+        s = ra.scene.make_scene(2, n=n)
+        with ra.InstancePipeline(max_instances=n, max_meshes=1) as p:
+            p.set_mesh_table(s["meshes"])
+            p.set_instances(s["pos"], s["rot"], s["scale"], s["mesh_id"])
+            assert_parity(p.run_host(s["planes"], s["cam_pos"]), run_oracle(oracle_mod, s), (order, n))
+
+
 def test_a_mesh_table_that_grows_from_one_entry_rerecords_and_gathers(ra, oracle_mod):
     """A table of ONE mesh is read as a scalar by the frame kernel (no id load, no gather: KernelArgs.one_mesh), and a recorded
     launch carries that choice in its arguments. The table growing to two entries and instances moving to the new one must give
