@@ -148,8 +148,17 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
   for (uint32_t v = 0; v < kMaxViews; ++v) {
     keep[v] = false; len[v] = 0; rank[v] = 0; excl_sum[v] = 0; vis_mask[v] = 0;
     if (v < a.n_views) {
-      const bool visible = active && !view_culled(box_h, box_c, a.view[v].planes);
-      const float dx = a.view[v].cam[0] - px, dy = a.view[v].cam[1] - py, dz = a.view[v].cam[2] - pz;
+      // everything of the view's arguments this block reads, fetched as ONE batch of scalar loads with one wait (left to itself the
+      // compiler fetched 16 plane words, waited, 8 more, waited, the camera, waited, the bitmap pointer, waited: four scalar
+      // round trips per view and wave in a kernel that is short of issue slots — profiles/r05_tile_head.txt, 6)
+      float view_planes[24];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) view_planes[k] = a.view[v].planes[k];
+      const float cam_x = a.view[v].cam[0], cam_y = a.view[v].cam[1], cam_z = a.view[v].cam[2];
+      uint32_t* const view_bitmap = a.view[v].bitmap;
+      asm volatile("" ::"s"(view_planes[0]), "s"(view_planes[16]), "s"(cam_x), "s"(view_bitmap));
+      const bool visible = active && !view_culled(box_h, box_c, view_planes);
+      const float dx = cam_x - px, dy = cam_y - py, dz = cam_z - pz;
       const float dist_sq = dx * dx + dy * dy + dz * dz;
       const bool far_lod = dist_sq > kLodDistSqThreshold;
       len[v] = far_lod ? mb.len1 : mb.len0;
@@ -165,23 +174,33 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
         s_wave_sum[v][wave] = incl;
       }
       // visibility bitmap: one 64-bit ballot per wave, written as two words
-      if (a.view[v].bitmap && lane < 2u) {
+      if (view_bitmap && lane < 2u) {
         const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
-        if (word < a.bitmap_words) a.view[v].bitmap[word] = (uint32_t)(vis_mask[v] >> (32u * lane));
+        if (word < a.bitmap_words) view_bitmap[word] = (uint32_t)(vis_mask[v] >> (32u * lane));
       }
     }
   }
   __syncthreads();
 
-  // ---- tile aggregates: thread v publishes view v ----
-  if (tid < a.n_views) {
-    uint32_t c = 0, s = 0;
+  // ---- tile aggregates: WAVE v publishes view v ----
+  // (round 2-4: THREAD v did, indexing the argument block per lane — the view's tag and pointers then come by vector loads from
+  //  the kernarg segment: three dependent round trips between the barrier and the accumulator's add, on every successor's
+  //  path. A wave's number is scalar: the same words are scalar loads, four waves publish their views side by side.)
+  {
+    const uint32_t pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    if (pv < a.n_views && lane == 0u) {
+      uint32_t c = 0, s = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < kWaves; ++w) { c += s_wave_count[tid][w]; s += s_wave_sum[tid][w]; }
-    publish_aggregate(a.view[tid], tile, c, s);
+      for (uint32_t w = 0; w < kWaves; ++w) { c += s_wave_count[pv][w]; s += s_wave_sum[pv][w]; }
+      publish_aggregate(a.view[pv], tile, c, s);
+    }
   }
 
   // ---- tile-local command assembly, every view ----
+  uint32_t view_first_instance[kMaxViews];  // (one batch of scalar loads, as above)
+#pragma unroll
+  for (uint32_t v = 0; v < kMaxViews; ++v) view_first_instance[v] = a.view[v].first_instance_base;
+  asm volatile("" ::"s"(view_first_instance[0]), "s"(view_first_instance[1]), "s"(view_first_instance[2]), "s"(view_first_instance[3]));
 #pragma unroll
   for (uint32_t v = 0; v < kMaxViews; ++v) {
     if (v < a.n_views && keep[v]) {
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
         if (w < wave) { off_count += s_wave_count[v][w]; off_sum += s_wave_sum[v][w]; }
       // {indexCount, firstIndex (tile-relative), vertexOffset, firstInstance = draw_index}: one ds_write_b128
       *reinterpret_cast<uint4*>(&s_cmd[v][(off_count + rank[v]) * kStaged]) =
-          make_uint4(len[v], off_sum + excl_sum[v], (uint32_t)vertex_offset, a.view[v].first_instance_base + i);
+          make_uint4(len[v], off_sum + excl_sum[v], (uint32_t)vertex_offset, view_first_instance[v] + i);
     }
   }
   __syncthreads();
