@@ -144,23 +144,32 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
   bool keep[kMaxViews];
   uint32_t len[kMaxViews], rank[kMaxViews], excl_sum[kMaxViews];
   unsigned long long vis_mask[kMaxViews];
+  // Everything of a view's arguments its block reads is fetched as ONE batch of scalar loads with one wait — and a view AHEAD:
+  // the batch of view v + 1 is issued when view v's plane tests are done (their registers are free then) and arrives under view
+  // v's ballots and scans. (Left to itself the compiler fetched 16 plane words, waited, 8 more, waited, the camera, waited, the
+  // bitmap pointer, waited: four scalar round trips per view and wave in a kernel that is short of issue slots —
+  // profiles/r05_tile_head.txt, 6.)
+  float view_planes[24], cam_x = 0.0f, cam_y = 0.0f, cam_z = 0.0f;
+  uint32_t* view_bitmap = nullptr;
+  auto fetch_view = [&](uint32_t v) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) view_planes[k] = a.view[v].planes[k];
+    cam_x = a.view[v].cam[0]; cam_y = a.view[v].cam[1]; cam_z = a.view[v].cam[2];
+    view_bitmap = a.view[v].bitmap;
+  };
+  if (a.n_views) fetch_view(0);
 #pragma unroll
   for (uint32_t v = 0; v < kMaxViews; ++v) {
     keep[v] = false; len[v] = 0; rank[v] = 0; excl_sum[v] = 0; vis_mask[v] = 0;
     if (v < a.n_views) {
-      // everything of the view's arguments this block reads, fetched as ONE batch of scalar loads with one wait (left to itself the
-      // compiler fetched 16 plane words, waited, 8 more, waited, the camera, waited, the bitmap pointer, waited: four scalar
-      // round trips per view and wave in a kernel that is short of issue slots — profiles/r05_tile_head.txt, 6)
-      float view_planes[24];
-#pragma unroll
-      for (int k = 0; k < 24; ++k) view_planes[k] = a.view[v].planes[k];
-      const float cam_x = a.view[v].cam[0], cam_y = a.view[v].cam[1], cam_z = a.view[v].cam[2];
-      uint32_t* const view_bitmap = a.view[v].bitmap;
-      asm volatile("" ::"s"(view_planes[0]), "s"(view_planes[16]), "s"(cam_x), "s"(view_bitmap));
+      asm volatile("" ::"s"(view_planes[0]), "s"(view_planes[16]), "s"(cam_x), "s"(view_bitmap));  // the batch is here: one wait
       const bool visible = active && !view_culled(box_h, box_c, view_planes);
       const float dx = cam_x - px, dy = cam_y - py, dz = cam_z - pz;
       const float dist_sq = dx * dx + dy * dy + dz * dz;
       const bool far_lod = dist_sq > kLodDistSqThreshold;
+      uint32_t* const this_bitmap = view_bitmap;
+      if (v + 1u < kMaxViews)
+        if (v + 1u < a.n_views) fetch_view(v + 1u);
       len[v] = far_lod ? mb.len1 : mb.len0;
       keep[v] = visible && len[v] > 0u;
       const uint32_t len_vis = visible ? len[v] : 0u;
@@ -174,9 +183,9 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
         s_wave_sum[v][wave] = incl;
       }
       // visibility bitmap: one 64-bit ballot per wave, written as two words
-      if (view_bitmap && lane < 2u) {
+      if (this_bitmap && lane < 2u) {
         const uint32_t word = (tile_first >> 5) + wave * 2u + lane;
-        if (word < a.bitmap_words) view_bitmap[word] = (uint32_t)(vis_mask[v] >> (32u * lane));
+        if (word < a.bitmap_words) this_bitmap[word] = (uint32_t)(vis_mask[v] >> (32u * lane));
       }
     }
   }
@@ -189,6 +198,10 @@ __global__ __launch_bounds__(kTile, kGeneral ? 4 : MIP_VIEWS_WAVES_PER_SIMD) voi
   {
     const uint32_t pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     if (pv < a.n_views && lane == 0u) {
+      {  // the view's prefix state in ONE batch of scalar loads (publish_aggregate reads these fields one basic block at a time)
+        const ViewArgs& vw = a.view[pv];
+        asm volatile("" ::"s"(vw.status0), "s"(vw.acc1), "s"(vw.groups_cap), "s"(vw.group_shift), "s"(vw.epoch));
+      }
       uint32_t c = 0, s = 0;
 #pragma unroll
       for (uint32_t w = 0; w < kWaves; ++w) { c += s_wave_count[pv][w]; s += s_wave_sum[pv][w]; }
